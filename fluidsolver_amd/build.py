@@ -1,0 +1,42 @@
+"""Builds libfluidsolver_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m fluidsolver_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfluidsolver_hip.so")
+SOURCES = ["passes.hip", "jacobi.hip", "context.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "fluidsolver.h")]
+
+# -ffp-contract=off: no FMA is formed, so every fp32 op rounds exactly like the CPU oracle.
+# hipcc's defaults already give correctly rounded fp32 divide/sqrt and keep denormals.
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,64 @@
+// common.h -- shared device/host helpers of libfluidsolver_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "fluidsolver.h"
+
+namespace fs {
+
+// Plane geometry as the kernels see it (by value in the kernel argument block).
+struct GK {
+    int W, H;      // global domain
+    int pitch;     // floats per row (multiple of 64)
+    int y0, rows;  // buffer holds global rows [y0, y0+rows)
+};
+
+inline GK make_gk(const fs_grid *g) { return GK{g->width, g->height, g->pitch, g->y0, g->rows}; }
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+int check_grid(const fs_grid *g);
+int hip_fail(hipError_t e, const char *what);
+
+#define FS_HIP(call)                                        \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return fs::hip_fail(e_, #call); \
+    } while (0)
+
+#define FS_LAUNCH_CHECK(name)                               \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) return fs::hip_fail(e_, name); \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ size_t row_off(const GK &g, int y)
+{
+    return (size_t)(y - g.y0) * (size_t)g.pitch;
+}
+// Row index clamped into the buffer: a caller that under-sized a halo gets wrong
+// values on that row (and FS_ERR_HALO from advect), never an out-of-bounds access.
+__device__ __forceinline__ int clamp_row(const GK &g, int y)
+{
+    return min(max(y, g.y0), g.y0 + g.rows - 1);
+}
+__device__ __forceinline__ bool is_boundary(const GK &g, int x, int y)
+{
+    // gid.x == 0 || gid.x >= width-1 || gid.y == 0 || gid.y >= height-1  (e.g. Shaders:91)
+    return x == 0 || x >= g.W - 1 || y == 0 || y >= g.H - 1;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// value of lane-1 / lane+1 of the wave (0 at the wave ends): one DPP operand, no LDS.
+__device__ __forceinline__ float from_lane_below(float x)  // lane i gets lane i-1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float x)  // lane i gets lane i+1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
+}
+
+}  // namespace fs

@@ -1,0 +1,291 @@
+// jacobi.hip -- temporally blocked Jacobi sweeps (pressureSolve / diffuse) for gfx950.
+//
+// The two hot loops of update() (Solver:506-517 diffuse, :533-541 pressureSolve) are N
+// back-to-back 5-point sweeps.  One sweep is pure HBM streaming (12 B/cell pressure,
+// 8 B/cell/plane diffuse); T sweeps fused in one launch move the same bytes once, so
+// the kernel turns from HBM-bound into VALU-bound.  The per-sweep arithmetic is
+// unchanged: every cell value is produced by exactly the reference's expression,
+// evaluated in the same order, so T fused sweeps equal T single sweeps bit for bit.
+//
+// CDNA4 mapping (register-resident tile, no LDS ping-pong):
+//   * a wave (64 lanes) owns a 256-column strip: lane l holds columns 4l..4l+3 of R
+//     rows in VGPRs (float4 per row) -> global loads/stores are 16 B/lane, 1 KiB per
+//     wave instruction, rows 256-byte aligned;
+//   * left/right neighbours inside a lane are registers; across lanes they are a DPP
+//     operand (wave_shr:1 / wave_shl:1 folded into the v_add), no LDS, no shuffle;
+//   * top/bottom neighbours inside a lane's R rows are registers; the two edge rows of
+//     each wave are exchanged with the waves above/below through a small
+//     double-buffered LDS array (2 x 16 B per lane per sweep), one barrier per sweep;
+//   * NW waves are stacked vertically: tile = 256 x (NW*R) cells; after T sweeps the
+//     inner (256-2*HX) x (NW*R-2*T) cells are exact and are stored, the rim is the
+//     redundantly computed halo (HX = T rounded up to 4 keeps stores 16-byte aligned).
+// Boundary cells (and cells outside the domain) do not depend on their neighbours:
+// pressure boundary = 0 (Shaders:201-204), diffuse boundary = copy (Shaders:91-94), so
+// inside the tile they are overwritten with that value every sweep.
+#include "common.h"
+
+namespace fs {
+
+enum { OP_PRESSURE = 0, OP_DIFFUSE = 1 };
+
+struct JacobiArgs {
+    GK g;
+    int yb, ye;        // global rows this launch must produce
+    const float *in;   // plane 0 of the input iterate (nullptr => all zero)
+    float *out;        // plane 0 of the output iterate
+    const float *div;  // pressure only
+    size_t stride;     // floats between planes (plane = blockIdx.z)
+    int T;             // sweeps in this launch (>= 1)
+    int HX;            // horizontal halo, multiple of 4, >= T
+    float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
+};
+
+template <int OP>
+__device__ __forceinline__ float sweep_cell(float c, float l, float r, float t, float b, float d, float a, float den)
+{
+    if (OP == OP_PRESSURE) {
+        return ((((d + l) + r) + t) + b) / 4.0f;       // Shaders:212
+    } else {
+        return (c + a * (((l + r) + t) + b)) / den;    // Shaders:103
+    }
+}
+
+template <int OP, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void k_jacobi_block(JacobiArgs A)
+{
+    constexpr int TW = 256;
+    constexpr int TH = NW * R;
+    __shared__ float4 xch[2][NW][2][64];
+
+    const GK g = A.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int OW = TW - 2 * A.HX;
+    const int OH = TH - 2 * A.T;
+    const int x0 = blockIdx.x * OW - A.HX;               // tile column 0 (global), multiple of 4
+    const int ry0 = A.yb + blockIdx.y * OH - A.T;        // tile row 0 (global)
+    const int gx = x0 + 4 * lane;                        // this lane's first column
+    const int wy0 = ry0 + wave * R;                      // this wave's first row
+    const size_t plane = (size_t)blockIdx.z * A.stride;
+    const float *in = A.in ? A.in + plane : nullptr;
+    float *out = A.out + plane;
+
+    const bool col_in_buf = gx >= 0 && gx < g.pitch;
+    // fixed (never updated) columns of this lane: domain boundary columns and everything outside
+    const bool fx0 = (gx + 0) <= 0 || (gx + 0) >= g.W - 1;
+    const bool fx1 = (gx + 1) <= 0 || (gx + 1) >= g.W - 1;
+    const bool fx2 = (gx + 2) <= 0 || (gx + 2) >= g.W - 1;
+    const bool fx3 = (gx + 3) <= 0 || (gx + 3) >= g.W - 1;
+    // wave-uniform: does this tile touch a fixed column at all?
+    const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1;
+
+    float4 p[R];
+    float4 d[R];
+    unsigned rowfixed = 0;  // bit i: row i is a boundary row or outside the domain (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int y = wy0 + i;
+        const bool row_in_buf = y >= g.y0 && y < g.y0 + g.rows;
+        const bool rf = y <= 0 || y >= g.H - 1;
+        rowfixed |= (rf ? 1u : 0u) << i;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_in_buf && col_in_buf) {
+            const size_t o = row_off(g, y) + gx;
+            if (in) pv = ld4(in + o);
+            if (OP == OP_PRESSURE) dv = ld4(A.div + o);
+        }
+        p[i] = pv;
+        d[i] = dv;
+    }
+
+    for (int s = 0; s < A.T; ++s) {
+        const int buf = s & 1;
+        xch[buf][wave][0][lane] = p[0];
+        xch[buf][wave][1][lane] = p[R - 1];
+        __syncthreads();
+        // rows above / below this wave's strip (tile rim rows have no neighbour: any value, never used)
+        float4 prev = wave > 0 ? xch[buf][wave - 1][1][lane] : p[0];
+        const float4 below = wave < NW - 1 ? xch[buf][wave + 1][0][lane] : p[R - 1];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float4 c = p[i];
+            const float4 nx = (i < R - 1) ? p[i + 1] : below;
+            const float l = from_lane_below(c.w);   // column 4l-1
+            const float r = from_lane_above(c.x);   // column 4l+4
+            float4 n;
+            n.x = sweep_cell<OP>(c.x, l, c.y, prev.x, nx.x, d[i].x, A.a, A.den);
+            n.y = sweep_cell<OP>(c.y, c.x, c.z, prev.y, nx.y, d[i].y, A.a, A.den);
+            n.z = sweep_cell<OP>(c.z, c.y, c.w, prev.z, nx.z, d[i].z, A.a, A.den);
+            n.w = sweep_cell<OP>(c.w, c.z, r, prev.w, nx.w, d[i].w, A.a, A.den);
+            // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
+            const float4 fixedv = OP == OP_PRESSURE ? make_float4(0.f, 0.f, 0.f, 0.f) : c;
+            if (edge_tile) {
+                if (fx0) n.x = fixedv.x;
+                if (fx1) n.y = fixedv.y;
+                if (fx2) n.z = fixedv.z;
+                if (fx3) n.w = fixedv.w;
+            }
+            if ((rowfixed >> i) & 1u) n = fixedv;
+            p[i] = n;
+            prev = c;
+        }
+    }
+
+    // store the exact inner region
+    const bool col_out = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
+    if (col_out) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ty = wave * R + i;
+            const int y = wy0 + i;
+            if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + gx, p[i]);
+        }
+    }
+}
+
+// tuning knobs (process-wide; see fs_config_set)
+static int g_block_depth = 8;
+
+template <int OP>
+static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
+                        int nplanes, size_t stride, int T, float a, float den, hipStream_t stream)
+{
+    constexpr int R = 8, NW = 8;
+    JacobiArgs A;
+    A.g = make_gk(g);
+    A.yb = yb;
+    A.ye = ye;
+    A.in = in;
+    A.out = out;
+    A.div = div;
+    A.stride = stride;
+    A.T = T;
+    A.HX = (T + 3) & ~3;
+    A.a = a;
+    A.den = den;
+    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * T;
+    dim3 grid((g->width + OW - 1) / OW, (ye - yb + OH - 1) / OH, nplanes);
+    hipLaunchKernelGGL((k_jacobi_block<OP, R, NW>), grid, dim3(NW * 64), 0, stream, A);
+    FS_LAUNCH_CHECK("k_jacobi_block");
+    return FS_OK;
+}
+
+// n sweeps ping-ponging a -> b -> a ...; launch j must leave rows [yb-rem, ye+rem) valid,
+// rem = sweeps still to come, clipped to the domain.
+template <int OP>
+static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
+                      size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream)
+{
+    const int need_lo = g->yb - n > 0 ? g->yb - n : 0;
+    const int need_hi = g->ye + n < g->height ? g->ye + n : g->height;
+    if (need_lo < g->y0 || need_hi > g->y0 + g->rows) {
+        set_error("jacobi: %d sweeps on rows [%d,%d) need rows [%d,%d) but the buffer holds [%d,%d)", n, g->yb,
+                  g->ye, need_lo, need_hi, g->y0, g->y0 + g->rows);
+        return FS_ERR_INVALID;
+    }
+    const int maxT = g_block_depth;
+    int rem = n;
+    float *src = a, *dst = b;
+    bool src_zero = a_is_zero;
+    int launches = 0;
+    while (rem > 0) {
+        const int T = rem < maxT ? rem : maxT;
+        rem -= T;
+        int yb = g->yb - rem, ye = g->ye + rem;
+        if (yb < 0) yb = 0;
+        if (ye > g->height) ye = g->height;
+        int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden, stream);
+        if (rc) return rc;
+        float *t = src; src = dst; dst = t;
+        src_zero = false;
+        ++launches;
+    }
+    if (result_in_b) *result_in_b = launches & 1;
+    return FS_OK;
+}
+
+int config_set_block_depth(int v)
+{
+    if (v < 1 || v > 24) return FS_ERR_INVALID;
+    g_block_depth = v;
+    return FS_OK;
+}
+int config_get_block_depth() { return g_block_depth; }
+
+}  // namespace fs
+
+using namespace fs;
+
+#define REQUIRE(cond, msg)                      \
+    do {                                        \
+        if (!(cond)) { fs::set_error("%s: %s", __func__, msg); return FS_ERR_INVALID; } \
+    } while (0)
+
+extern "C" {
+
+int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero,
+                         int *result_in_b, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(div && pa && pb && pa != pb, "bad pointers");
+    REQUIRE(n >= 0, "negative sweep count");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb) return FS_OK;
+    if (n == 0) {
+        if (p_is_zero) return fs_k_clear(g, pa, 1, 0, stream);
+        return FS_OK;
+    }
+    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream);
+}
+
+int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(div && p && pOut && p != pOut, "bad pointers");
+    if (g->ye <= g->yb) return FS_OK;
+    // one sweep: a is only read
+    return run_sweeps<OP_PRESSURE>(g, div, const_cast<float *>(p), pOut, false, 1, 0, 0.f, 1.f, 1, nullptr,
+                                   (hipStream_t)stream);
+}
+
+static void diffuse_coeffs(const fs_grid *g, float viscosity, float dt, float *a, float *den)
+{
+    // Shaders:96  a = deltaTime * viscosity * width * height  (uint -> float)
+    *a = ((dt * viscosity) * (float)(unsigned)g->width) * (float)(unsigned)g->height;
+    *den = 1.0f + 4.0f * *a;  // Shaders:103
+}
+
+int fs_k_diffuse_n(const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
+                   float deltaTime, int n, int *result_in_b, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(a && b && a != b, "bad pointers");
+    REQUIRE(nplanes >= 1 && nplanes <= 4, "nplanes must be 1..4");
+    REQUIRE(n >= 0, "negative sweep count");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb || n == 0) return FS_OK;
+    float ca, cden;
+    diffuse_coeffs(g, viscosity, deltaTime, &ca, &cden);
+    return run_sweeps<OP_DIFFUSE>(g, nullptr, a, b, false, nplanes, plane_stride, ca, cden, n, result_in_b,
+                                  (hipStream_t)stream);
+}
+
+int fs_k_diffuse(const fs_grid *g, const float *in, float *out, int nplanes, size_t plane_stride, float viscosity,
+                 float deltaTime, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(in && out && in != out, "bad pointers");
+    REQUIRE(nplanes >= 1 && nplanes <= 4, "nplanes must be 1..4");
+    if (g->ye <= g->yb) return FS_OK;
+    float ca, cden;
+    diffuse_coeffs(g, viscosity, deltaTime, &ca, &cden);
+    return run_sweeps<OP_DIFFUSE>(g, nullptr, const_cast<float *>(in), out, false, nplanes, plane_stride, ca, cden, 1,
+                                  nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

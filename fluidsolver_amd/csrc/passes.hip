@@ -1,0 +1,549 @@
+// passes.hip -- single-pass kernels of the stable-fluids step for gfx950.
+//
+// Every kernel here is a streaming pass bounded by HBM bandwidth.  Layout: planar
+// fp32, 256-byte-aligned rows (pitch % 64 == 0).  One thread owns 4 consecutive cells
+// of one row, so every center/top/bottom access is one aligned 16-byte load per lane
+// (1 KiB per wave instruction, the widest coalesced form on CDNA4); the two cells
+// beside the quad come from one extra dword load each (L1/L2 hits).  A workgroup is
+// 64 x 4 threads = 256 columns x 4 rows, so the rows it re-reads as top/bottom
+// neighbours are shared through the vector L1.
+//
+// Arithmetic follows the reference shaders operation by operation (cited per kernel,
+// Shaders = fluidSolver/Shaders/FluidShaders.metal); the library is compiled with
+// -ffp-contract=off so no FMA is formed and results are bit-identical to the oracle.
+#include "common.h"
+#include <math.h>
+
+namespace fs {
+
+constexpr int BX = 64;  // lanes along x (each 4 cells)
+constexpr int BY = 4;   // rows per workgroup
+
+struct Quad {
+    int x, y;
+    bool ok;
+};
+
+__device__ __forceinline__ Quad quad_of_thread(const GK &g, int yb, int ye)
+{
+    Quad q;
+    q.x = (blockIdx.x * BX + threadIdx.x) * 4;
+    q.y = yb + blockIdx.y * BY + threadIdx.y;
+    q.ok = q.x < g.pitch && q.y < ye;
+    return q;
+}
+
+// center quad plus the cells left of .x and right of .w (0 outside the row)
+struct RowN {
+    float4 c;
+    float l, r;
+};
+__device__ __forceinline__ RowN load_row_nb(const float *p, const GK &g, int x, int y)
+{
+    const float *row = p + row_off(g, y);
+    RowN n;
+    n.c = ld4(row + x);
+    n.l = x > 0 ? row[x - 1] : 0.0f;
+    n.r = x + 4 < g.pitch ? row[x + 4] : 0.0f;
+    return n;
+}
+__device__ __forceinline__ float4 lefts(const RowN &n) { return make_float4(n.l, n.c.x, n.c.y, n.c.z); }
+__device__ __forceinline__ float4 rights(const RowN &n) { return make_float4(n.c.y, n.c.z, n.c.w, n.r); }
+
+#define FOR4(expr_x, expr_y, expr_z, expr_w) \
+    do { expr_x; expr_y; expr_z; expr_w; } while (0)
+
+// ---------------------------------------------------------------------------
+// divergence, Shaders:162-181:  div = -0.5*((r.x - l.x) + (b.y - t.y)); boundary 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_divergence(GK g, int yb, int ye, const float *__restrict__ u,
+                                                    const float *__restrict__ v, float *__restrict__ div)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    RowN un = load_row_nb(u, g, q.x, q.y);
+    float4 vt = ld4(v + row_off(g, clamp_row(g, q.y - 1)) + q.x);
+    float4 vb = ld4(v + row_off(g, clamp_row(g, q.y + 1)) + q.x);
+    float4 ul = lefts(un), ur = rights(un);
+    float4 o;
+    o.x = is_boundary(g, q.x + 0, q.y) ? 0.0f : -0.5f * ((ur.x - ul.x) + (vb.x - vt.x));
+    o.y = is_boundary(g, q.x + 1, q.y) ? 0.0f : -0.5f * ((ur.y - ul.y) + (vb.y - vt.y));
+    o.z = is_boundary(g, q.x + 2, q.y) ? 0.0f : -0.5f * ((ur.z - ul.z) + (vb.z - vt.z));
+    o.w = is_boundary(g, q.x + 3, q.y) ? 0.0f : -0.5f * ((ur.w - ul.w) + (vb.w - vt.w));
+    st4(div + row_off(g, q.y) + q.x, o);
+}
+
+// ---------------------------------------------------------------------------
+// calculateVorticity, Shaders:256-275: curl = (b.x - t.x) - (r.y - l.y); boundary 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vorticity(GK g, int yb, int ye, const float *__restrict__ u,
+                                                   const float *__restrict__ v, float *__restrict__ w)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    RowN vn = load_row_nb(v, g, q.x, q.y);
+    float4 ut = ld4(u + row_off(g, clamp_row(g, q.y - 1)) + q.x);
+    float4 ub = ld4(u + row_off(g, clamp_row(g, q.y + 1)) + q.x);
+    float4 vl = lefts(vn), vr = rights(vn);
+    float4 o;
+    o.x = is_boundary(g, q.x + 0, q.y) ? 0.0f : (ub.x - ut.x) - (vr.x - vl.x);
+    o.y = is_boundary(g, q.x + 1, q.y) ? 0.0f : (ub.y - ut.y) - (vr.y - vl.y);
+    o.z = is_boundary(g, q.x + 2, q.y) ? 0.0f : (ub.z - ut.z) - (vr.z - vl.z);
+    o.w = is_boundary(g, q.x + 3, q.y) ? 0.0f : (ub.w - ut.w) - (vr.w - vl.w);
+    st4(w + row_off(g, q.y) + q.x, o);
+}
+
+// ---------------------------------------------------------------------------
+// subtractGradient, Shaders:225-245: vel.x -= 0.5*(r-l); vel.y -= 0.5*(b-t); boundary untouched
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_subtract_gradient(GK g, int yb, int ye, const float *__restrict__ p,
+                                                           float *__restrict__ u, float *__restrict__ v)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    RowN pn = load_row_nb(p, g, q.x, q.y);
+    float4 pt = ld4(p + row_off(g, clamp_row(g, q.y - 1)) + q.x);
+    float4 pb = ld4(p + row_off(g, clamp_row(g, q.y + 1)) + q.x);
+    float4 pl = lefts(pn), pr = rights(pn);
+    size_t o = row_off(g, q.y) + q.x;
+    float4 uu = ld4(u + o), vv = ld4(v + o);
+    if (!is_boundary(g, q.x + 0, q.y)) { uu.x = uu.x - 0.5f * (pr.x - pl.x); vv.x = vv.x - 0.5f * (pb.x - pt.x); }
+    if (!is_boundary(g, q.x + 1, q.y)) { uu.y = uu.y - 0.5f * (pr.y - pl.y); vv.y = vv.y - 0.5f * (pb.y - pt.y); }
+    if (!is_boundary(g, q.x + 2, q.y)) { uu.z = uu.z - 0.5f * (pr.z - pl.z); vv.z = vv.z - 0.5f * (pb.z - pt.z); }
+    if (!is_boundary(g, q.x + 3, q.y)) { uu.w = uu.w - 0.5f * (pr.w - pl.w); vv.w = vv.w - 0.5f * (pb.w - pt.w); }
+    st4(u + o, uu);
+    st4(v + o, vv);
+}
+
+// ---------------------------------------------------------------------------
+// applyVorticity, Shaders:288-316
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void vort_force(float l, float r, float t, float b, float c, float strength, float dt,
+                                           float &uu, float &vv)
+{
+    float gx = fabsf(r) - fabsf(l);              // :301-307
+    float gy = fabsf(b) - fabsf(t);
+    float glen = sqrtf(gx * gx + gy * gy) + 0.00001f;  // :308
+    gx = gx / glen;                              // :309
+    gy = gy / glen;
+    float sc = strength * c;                     // :311
+    uu = uu + (sc * gy) * dt;                    // :314
+    vv = vv + (sc * (-gx)) * dt;
+}
+
+__global__ __launch_bounds__(256) void k_apply_vorticity(GK g, int yb, int ye, const float *__restrict__ w,
+                                                         float *__restrict__ u, float *__restrict__ v,
+                                                         float strength, float dt)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    RowN wn = load_row_nb(w, g, q.x, q.y);
+    float4 wt = ld4(w + row_off(g, clamp_row(g, q.y - 1)) + q.x);
+    float4 wb = ld4(w + row_off(g, clamp_row(g, q.y + 1)) + q.x);
+    float4 wl = lefts(wn), wr = rights(wn);
+    size_t o = row_off(g, q.y) + q.x;
+    float4 uu = ld4(u + o), vv = ld4(v + o);
+    if (!is_boundary(g, q.x + 0, q.y)) vort_force(wl.x, wr.x, wt.x, wb.x, wn.c.x, strength, dt, uu.x, vv.x);
+    if (!is_boundary(g, q.x + 1, q.y)) vort_force(wl.y, wr.y, wt.y, wb.y, wn.c.y, strength, dt, uu.y, vv.y);
+    if (!is_boundary(g, q.x + 2, q.y)) vort_force(wl.z, wr.z, wt.z, wb.z, wn.c.z, strength, dt, uu.z, vv.z);
+    if (!is_boundary(g, q.x + 3, q.y)) vort_force(wl.w, wr.w, wt.w, wb.w, wn.c.w, strength, dt, uu.w, vv.w);
+    st4(u + o, uu);
+    st4(v + o, vv);
+}
+
+// ---------------------------------------------------------------------------
+// fadeDensity, Shaders:326-334: d = max(d*(1-fade), 0), every cell; planes on blockIdx.z
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fade(GK g, int yb, int ye, float *__restrict__ d, size_t stride, float k)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    float *p = d + (size_t)blockIdx.z * stride + row_off(g, q.y) + q.x;
+    float4 x = ld4(p);
+    x.x = fmaxf(x.x * k, 0.0f);
+    x.y = fmaxf(x.y * k, 0.0f);
+    x.z = fmaxf(x.z * k, 0.0f);
+    x.w = fmaxf(x.w * k, 0.0f);
+    st4(p, x);
+}
+
+// clearTexture, Shaders:343-346
+__global__ __launch_bounds__(256) void k_clear(GK g, int yb, int ye, float *__restrict__ t, size_t stride)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    st4(t + (size_t)blockIdx.z * stride + row_off(g, q.y) + q.x, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// ---------------------------------------------------------------------------
+// render kernels, Shaders:357-414 (display = 4 planes R,G,B,A)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_render_density(GK g, int yb, int ye, const float *__restrict__ d,
+                                                        size_t dstride, int dplanes, float *__restrict__ out,
+                                                        size_t ostride, float brightness)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    size_t o = row_off(g, q.y) + q.x;
+    // vorticity display mode binds a 1-channel field whose .gba are 0 (Solver:613-618)
+    for (int c = 0; c < 3; ++c) {
+        float4 x = c < dplanes ? ld4(d + c * dstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x.x *= brightness; x.y *= brightness; x.z *= brightness; x.w *= brightness;   // :363
+        st4(out + c * ostride + o, x);
+    }
+    st4(out + 3 * ostride + o, make_float4(1.f, 1.f, 1.f, 1.f));                       // :364
+}
+
+template <bool SPEED_ONLY>
+__global__ __launch_bounds__(256) void k_render_velocity(GK g, int yb, int ye, const float *__restrict__ u,
+                                                         const float *__restrict__ v, float *__restrict__ out,
+                                                         size_t ostride, float scale)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    size_t o = row_off(g, q.y) + q.x;
+    float4 a = ld4(u + o), b = ld4(v + o);
+    float4 sp;
+    sp.x = sqrtf(a.x * a.x + b.x * b.x);   // :384 / :411 length(vel)
+    sp.y = sqrtf(a.y * a.y + b.y * b.y);
+    sp.z = sqrtf(a.z * a.z + b.z * b.z);
+    sp.w = sqrtf(a.w * a.w + b.w * b.w);
+    sp.x *= scale; sp.y *= scale; sp.z *= scale; sp.w *= scale;
+    if (SPEED_ONLY) {                       // :411-413
+        st4(out + o, sp);
+        st4(out + ostride + o, sp);
+    } else {                                // :389-391
+        st4(out + o, make_float4(a.x * scale + 0.5f, a.y * scale + 0.5f, a.z * scale + 0.5f, a.w * scale + 0.5f));
+        st4(out + ostride + o,
+            make_float4(b.x * scale + 0.5f, b.y * scale + 0.5f, b.z * scale + 0.5f, b.w * scale + 0.5f));
+    }
+    st4(out + 2 * ostride + o, sp);
+    st4(out + 3 * ostride + o, make_float4(1.f, 1.f, 1.f, 1.f));
+}
+
+// ---------------------------------------------------------------------------
+// advect, Shaders:118-151.  One thread per cell: the velocity read and the output
+// write are coalesced dwords; the 4 bilinear taps per plane are a data-dependent
+// gather served by L1/L2 (neighbouring lanes trace to neighbouring cells).
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const float *__restrict__ u,
+                                                const float *__restrict__ v, const float *in,
+                                                float *__restrict__ out, size_t stride, float dt, int *err)
+{
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = yb + blockIdx.y * 4 + threadIdx.y;
+    if (x >= g.W || y >= ye) return;
+    size_t o = row_off(g, y) + x;
+    if (is_boundary(g, x, y)) {                               // :127-130
+#pragma unroll
+        for (int c = 0; c < NP; ++c) out[c * stride + o] = in[c * stride + o];
+        return;
+    }
+    float posx = (float)x - u[o] * dt;                        // :132-133
+    float posy = (float)y - v[o] * dt;
+    posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
+    posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
+    int i0x = (int)floorf(posx), i0y = (int)floorf(posy);     // :140
+    float sx = posx - (float)i0x, sy = posy - (float)i0y;     // :142
+    int i1y = i0y + 1;
+    if (i0y < g.y0 || i1y >= g.y0 + g.rows) {                 // slab halo too small: flag, stay in bounds
+        if (err) atomicOr(err, 1);
+        i0y = clamp_row(g, i0y);
+        i1y = clamp_row(g, i1y);
+    }
+    size_t o0 = row_off(g, i0y) + i0x, o1 = row_off(g, i1y) + i0x;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const float *p = in + c * stride;
+        float q00 = p[o0], q10 = p[o0 + 1];                   // :144-147
+        float q01 = p[o1], q11 = p[o1 + 1];
+        float m0 = q00 + (q10 - q00) * sx;                    // :149 mix(mix(),mix(),s.y)
+        float m1 = q01 + (q11 - q01) * sx;
+        out[c * stride + o] = m0 + (m1 - m0) * sy;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// addForces, Shaders:43-69, on the splat's bounding box only (the reference launches
+// the full grid for <= ~7.9k touched cells).  exp is evaluated in fp64 and rounded
+// once, i.e. a correctly rounded fp32 exp.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_add_forces(GK g, int bx0, int by0, int bx1, int by1, float *__restrict__ u,
+                                                    float *__restrict__ v, float *__restrict__ r,
+                                                    float *__restrict__ gch, float *__restrict__ b, float px,
+                                                    float py, float fx, float fy, float cr, float cg, float cb,
+                                                    float radius, float dt)
+{
+    int x = bx0 + blockIdx.x * 64 + threadIdx.x;
+    int y = by0 + blockIdx.y * 4 + threadIdx.y;
+    if (x > bx1 || y > by1) return;
+    float dx = (float)x - px, dy = (float)y - py;             // :52-53
+    float dist = sqrtf(dx * dx + dy * dy);                    // :54
+    if (dist < radius) {                                      // :56
+        float arg = ((-dist) * dist) / ((2.0f * radius) * radius);   // :57
+        float infl = (float)exp((double)arg);
+        size_t o = row_off(g, y) + x;
+        u[o] = u[o] + (fx * infl) * dt;                       // :61
+        v[o] = v[o] + (fy * infl) * dt;
+        r[o] = r[o] + (cr * infl) * dt;                       // :66
+        gch[o] = gch[o] + (cg * infl) * dt;
+        b[o] = b[o] + (cb * infl) * dt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tracers: ParticleSystem.update(), Part:242-304 + lookup of Solver:648-657. SoA.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_particles(GK g, const float *__restrict__ u, const float *__restrict__ v,
+                                                   fs_particle_params pp, float eff, long n, float *__restrict__ px,
+                                                   float *__restrict__ py, float *__restrict__ vx,
+                                                   float *__restrict__ vy, float *__restrict__ life,
+                                                   const float *__restrict__ mass, float *__restrict__ age)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float l = life[i];
+    if (l == 0.0f) return;                                    // dead slot
+    const float invW = 1.0f / pp.windowW, invH = 1.0f / pp.windowH;    // Part:245-248
+    const float gw = (float)g.W, gh = (float)g.H;
+    float x = px[i], y = py[i], a = age[i];
+    float nx = x * invW, ny = y * invH;                       // Part:255
+    int cx = (int)fmaxf(0.0f, fminf(gw - 1.0f, nx * gw));     // Solver:650
+    int cy = (int)fmaxf(0.0f, fminf(gh - 1.0f, ny * gh));     // Solver:651
+    cy = clamp_row(g, cy);
+    size_t o = row_off(g, cy) + cx;
+    float fvx = u[o] / gw, fvy = v[o] / gh;                   // build's normalisation (fluidsolver.h)
+    float ageDecay = fmaxf(0.0f, 1.0f - a * pp.fluidDecayRate);        // Part:259
+    float k = (mass[i] * eff) * ageDecay;                     // Part:271
+    float fcx = (fvx * k) * pp.windowW, fcy = (fvy * k) * pp.windowH;
+    float em = pp.momentum + (1.0f - pp.momentum) * fminf(1.0f, a * 2.0f);   // Part:272
+    float nvx = fcx + vx[i] * em, nvy = fcy + vy[i] * em;     // Part:273-275
+    float npx = x + nvx, npy = y + nvy;                       // Part:276
+    const float margin = 50.0f;                               // Part:282
+    if (npx < -margin || npx > pp.windowW + margin || npy < -margin || npy > pp.windowH + margin) l = 0.0f;
+    l = l * 0.999f;                                           // Part:291
+    if (l < 0.01f) l = 0.0f;                                  // Part:294-295
+    vx[i] = nvx; vy[i] = nvy; px[i] = npx; py[i] = npy;
+    age[i] = a + 1.0f / 60.0f;                                // Part:279
+    life[i] = l;
+}
+
+// max |plane| over rows [yb,ye): wave shuffle reduce, one atomicMax per wave (non-negative
+// floats order like their bit patterns).
+__global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const float *__restrict__ p, unsigned *out)
+{
+    float m = 0.0f;
+    int nq = g.W / 4;  // whole quads; tail handled below
+    for (int y = yb + blockIdx.x; y < ye; y += gridDim.x) {
+        const float *row = p + row_off(g, y);
+        for (int qx = threadIdx.x; qx < nq; qx += 256) {
+            float4 a = ld4(row + 4 * qx);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+        for (int x = nq * 4 + threadIdx.x; x < g.W; x += 256) m = fmaxf(m, fabsf(row[x]));
+    }
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+static inline dim3 quad_grid(const fs_grid *g, int nplanes)
+{
+    int qx = g->pitch / 4;
+    return dim3((qx + BX - 1) / BX, (g->ye - g->yb + BY - 1) / BY, nplanes);
+}
+static const dim3 kBlock(BX, BY, 1);
+
+}  // namespace fs
+
+using namespace fs;
+
+#define STREAM ((hipStream_t)stream)
+#define REQUIRE(cond, msg)                      \
+    do {                                        \
+        if (!(cond)) { fs::set_error("%s: %s", __func__, msg); return FS_ERR_INVALID; } \
+    } while (0)
+#define CHECK_GRID(g)                 \
+    do {                              \
+        int rc_ = fs::check_grid(g);  \
+        if (rc_) return rc_;          \
+    } while (0)
+#define EMPTY_OK(g) \
+    if ((g)->ye <= (g)->yb) return FS_OK
+
+extern "C" {
+
+int fs_k_divergence(const fs_grid *g, const float *u, const float *v, float *div, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && div, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_divergence, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v, div);
+    FS_LAUNCH_CHECK("k_divergence");
+    return FS_OK;
+}
+
+int fs_k_calculateVorticity(const fs_grid *g, const float *u, const float *v, float *vort, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && vort, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_vorticity, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v, vort);
+    FS_LAUNCH_CHECK("k_vorticity");
+    return FS_OK;
+}
+
+int fs_k_subtractGradient(const fs_grid *g, const float *p, float *u, float *v, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(p && u && v, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_subtract_gradient, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, p, u, v);
+    FS_LAUNCH_CHECK("k_subtract_gradient");
+    return FS_OK;
+}
+
+int fs_k_applyVorticity(const fs_grid *g, const float *vort, float *u, float *v, float strength, float deltaTime,
+                        void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(vort && u && v, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_apply_vorticity, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, vort, u, v,
+                       strength, deltaTime);
+    FS_LAUNCH_CHECK("k_apply_vorticity");
+    return FS_OK;
+}
+
+int fs_k_fadeDensity(const fs_grid *g, float *d, int nplanes, size_t plane_stride, float fadeRate, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(d && nplanes >= 1, "bad arguments");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_fade, quad_grid(g, nplanes), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, d, plane_stride,
+                       1.0f - fadeRate);  // Shaders:331
+    FS_LAUNCH_CHECK("k_fade");
+    return FS_OK;
+}
+
+int fs_k_clear(const fs_grid *g, float *t, int nplanes, size_t plane_stride, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(t && nplanes >= 1, "bad arguments");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_clear, quad_grid(g, nplanes), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, t, plane_stride);
+    FS_LAUNCH_CHECK("k_clear");
+    return FS_OK;
+}
+
+int fs_k_renderDensity(const fs_grid *g, const float *d, size_t d_stride, int d_planes, float *out4,
+                       size_t out_stride, float brightness, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(d && out4 && d_planes >= 1 && d_planes <= 3, "bad arguments");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_render_density, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, d, d_stride,
+                       d_planes, out4, out_stride, brightness);
+    FS_LAUNCH_CHECK("k_render_density");
+    return FS_OK;
+}
+
+int fs_k_renderVelocity(const fs_grid *g, const float *u, const float *v, float *out4, size_t out_stride,
+                        float scale, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && out4, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_render_velocity<false>, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v,
+                       out4, out_stride, scale);
+    FS_LAUNCH_CHECK("k_render_velocity");
+    return FS_OK;
+}
+
+int fs_k_renderSpeed(const fs_grid *g, const float *u, const float *v, float *out4, size_t out_stride, float scale,
+                     void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && out4, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_render_velocity<true>, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v,
+                       out4, out_stride, scale);
+    FS_LAUNCH_CHECK("k_render_speed");
+    return FS_OK;
+}
+
+int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
+                size_t plane_stride, float deltaTime, int *err_flag, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && in && out, "null pointer");
+    REQUIRE(nplanes >= 1 && nplanes <= 3, "nplanes must be 1..3");
+    REQUIRE(in != out, "advect cannot run in place");
+    EMPTY_OK(g);
+    dim3 grid((g->width + 63) / 64, (g->ye - g->yb + 3) / 4, 1);
+    GK gk = make_gk(g);
+    switch (nplanes) {
+    case 1: hipLaunchKernelGGL(k_advect<1>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
+    case 2: hipLaunchKernelGGL(k_advect<2>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
+    default: hipLaunchKernelGGL(k_advect<3>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
+    }
+    FS_LAUNCH_CHECK("k_advect");
+    return FS_OK;
+}
+
+int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, float pos_x, float pos_y,
+                   float force_x, float force_y, float color_r, float color_g, float color_b, float radius,
+                   float deltaTime, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && r && gch && b, "null pointer");
+    REQUIRE(isfinite(pos_x) && isfinite(pos_y) && isfinite(radius), "non-finite splat geometry");
+    EMPTY_OK(g);
+    if (!(radius > 0.0f)) return FS_OK;  // dist < radius can never hold
+    // every cell with dist < radius lies in [pos-radius, pos+radius]
+    double lo_x = floor((double)pos_x - radius), hi_x = ceil((double)pos_x + radius);
+    double lo_y = floor((double)pos_y - radius), hi_y = ceil((double)pos_y + radius);
+    if (hi_x < 0 || hi_y < g->yb || lo_x > g->width - 1 || lo_y > g->ye - 1) return FS_OK;
+    int bx0 = (int)fmax(lo_x, 0.0), bx1 = (int)fmin(hi_x, (double)g->width - 1);
+    int by0 = (int)fmax(lo_y, (double)g->yb), by1 = (int)fmin(hi_y, (double)g->ye - 1);
+    if (bx1 < bx0 || by1 < by0) return FS_OK;
+    dim3 grid((bx1 - bx0 + 64) / 64, (by1 - by0 + 4) / 4, 1);
+    hipLaunchKernelGGL(k_add_forces, grid, kBlock, 0, STREAM, make_gk(g), bx0, by0, bx1, by1, u, v, r, gch, b, pos_x,
+                       pos_y, force_x, force_y, color_r, color_g, color_b, radius, deltaTime);
+    FS_LAUNCH_CHECK("k_add_forces");
+    return FS_OK;
+}
+
+int fs_k_particles_update(const fs_grid *g, const float *u, const float *v, const fs_particle_params *pp, long n,
+                          float *px, float *py, float *vx, float *vy, float *life, const float *mass, float *age,
+                          void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && pp, "null pointer");
+    REQUIRE(n >= 0, "negative particle count");
+    if (n == 0) return FS_OK;
+    REQUIRE(px && py && vx && vy && life && mass && age, "null particle array");
+    REQUIRE(g->y0 == 0 && g->rows == g->height, "tracers need the whole grid on this GPU");
+    // Part:262-268
+    float eff = pp->linkToViscosity ? 0.1f + (pp->viscosity / 0.01f) * 0.9f : pp->fluidForce;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_particles, dim3(blocks), dim3(256), 0, STREAM, make_gk(g), u, v, *pp, eff, n, px, py, vx,
+                       vy, life, mass, age);
+    FS_LAUNCH_CHECK("k_particles");
+    return FS_OK;
+}
+
+int fs_k_max_abs(const fs_grid *g, const float *plane, float *out_dev, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(plane && out_dev, "null pointer");
+    EMPTY_OK(g);
+    int blocks = g->ye - g->yb;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_max_abs, dim3(blocks), dim3(256), 0, STREAM, make_gk(g), g->yb, g->ye, plane,
+                       reinterpret_cast<unsigned *>(out_dev));
+    FS_LAUNCH_CHECK("k_max_abs");
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+/*
+ * fluidsolver.h -- C ABI of libfluidsolver_hip.so
+ *
+ * MI355X (gfx950) implementation of the per-frame stable-fluids step of
+ * aidancornelius/fluidSolver: FluidSolver.update() + applyForce() + the tracer
+ * update.  The reference has no FFI; its boundary is the Swift -> Metal call
+ * pattern (13 compute kernels looked up BY NAME, FluidSolver.swift:288-300, then
+ * setTexture/setBytes/dispatchThreads per stage, e.g. :534-538).  This header is
+ * what a host binds instead of those Metal dispatches.  Citations are into
+ * /root/reference/:
+ *     Shaders = fluidSolver/Shaders/FluidShaders.metal
+ *     Solver  = fluidSolver/Models/FluidSolver.swift
+ *     Part    = fluidSolver/Models/ParticleSystem.swift
+ *
+ * Two layers:
+ *   1. fs_k_*   one entry per reference kernel name, on caller-owned DEVICE
+ *               buffers (plain pointers + an fs_grid), asynchronous on a HIP
+ *               stream.  A host can swap a single stage.  The *_n forms run n
+ *               Jacobi sweeps temporally blocked (same per-sweep arithmetic).
+ *   2. fs_*     an opaque solver context that owns all device memory and runs
+ *               the whole update() as a captured hipGraph.
+ *
+ * Conventions
+ *   - Every function returns 0 (FS_OK) or a negative FS_ERR_* code and never
+ *     aborts the process (the reference fatalError()s on set-up failure,
+ *     Solver:270,277,302, and silently returns on encode failure, :349,:445,:478).
+ *   - All arithmetic is strict IEEE fp32 (no FMA contraction, correctly rounded
+ *     divide/sqrt; the splat's exp is evaluated in fp64 and rounded once).
+ *   - Fields are PLANAR fp32: velocity = 2 planes (u,v), dye = 3 planes (r,g,b),
+ *     pressure / divergence / vorticity = 1 plane.  The reference's rgba32Float
+ *     texels (Solver:323-330) carry dead channels (velocity .zw, dye alpha) which
+ *     are dropped.
+ *   - Neighbour naming follows the shaders: left=(x-1,y) right=(x+1,y)
+ *     top=(x,y-1) bottom=(x,y+1).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Calls are asynchronous and execute in call order on their stream, like the
+ *     reference's single MTLCommandQueue (Solver:273).  A context is not
+ *     thread-safe; callers serialise (the reference lives on the main thread).
+ */
+#ifndef FLUIDSOLVER_H
+#define FLUIDSOLVER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_OK            0
+#define FS_ERR_INVALID  -1   /* bad argument / shape */
+#define FS_ERR_HIP      -2   /* a HIP runtime call failed (see fs_last_error) */
+#define FS_ERR_NOMEM    -3
+#define FS_ERR_HALO     -4   /* advect backtrace left the buffered rows (slab halo too small) */
+#define FS_ERR_STATE    -5
+
+/* Geometry of one plane as it lies in device memory.
+ * A single GPU holds the whole grid: {W, H, pitch, 0, H, 0, H}.
+ * A row slab of a multi-GPU run holds global rows [y0, y0+rows) (owned rows plus
+ * ghost rows) and computes output rows [yb, ye); boundary tests always use the
+ * GLOBAL width/height, exactly like gid vs get_width()/get_height() in the
+ * shaders (e.g. Shaders:91). */
+typedef struct fs_grid {
+    int width, height; /* global domain, cells */
+    int pitch;         /* floats per buffer row; multiple of 64 (256-byte rows) and >= width */
+    int y0, rows;      /* buffer row 0 is global row y0; the buffer holds `rows` rows */
+    int yb, ye;        /* rows to compute, global, y0 <= yb <= ye <= y0+rows */
+} fs_grid;
+
+/* smallest legal pitch for a width */
+int fs_pitch_for_width(int width);
+
+/* Process-wide tuning knobs of the per-kernel layer (keys: FS_OPT_BLOCK_DEPTH = sweeps fused
+ * per Jacobi launch, 1..24, default 8).  No reference counterpart. */
+int fs_config_set(int key, int value);
+int fs_config_get(int key);
+
+/* -------------------------------------------------------------------------
+ * Layer 1: per-kernel entry points (device pointers).
+ * Multi-plane arguments take the pointer of plane 0 and `plane_stride` floats
+ * between planes.
+ * ---------------------------------------------------------------------- */
+
+/* replaces kernel addForces, Shaders:43-69 (buffers 0-4: position, force, color,
+ * radius, deltaTime; Solver:444-470).  Launched on the splat's bounding box only. */
+int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, float *b,
+                   float pos_x, float pos_y, float force_x, float force_y,
+                   float color_r, float color_g, float color_b,
+                   float radius, float deltaTime, void *stream);
+
+/* replaces kernel diffuse, Shaders:82-105 (buffer 0 viscosity, 1 deltaTime), one sweep */
+int fs_k_diffuse(const fs_grid *g, const float *in, float *out, int nplanes, size_t plane_stride,
+                 float viscosity, float deltaTime, void *stream);
+
+/* n sweeps of diffuse, temporally blocked (the loop of Solver:506-517 / :563-573).
+ * Ping-pongs between a (holds the input) and b; *result_in_b says where the result is.
+ * Needs input rows [yb-n, ye+n) (clipped to the domain) present in the buffer. */
+int fs_k_diffuse_n(const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride,
+                   float viscosity, float deltaTime, int n, int *result_in_b, void *stream);
+
+/* replaces kernel advect, Shaders:118-151 (buffer 0 deltaTime).  `in` may alias u/v
+ * planes (velocity self-advection, Solver:550-556).  err_flag (device int, may be
+ * NULL) is set non-zero if a tap needed a row outside the buffer (slab halo too small;
+ * the access is clamped, never out of bounds). */
+int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out,
+                int nplanes, size_t plane_stride, float deltaTime, int *err_flag, void *stream);
+
+/* replaces kernel divergence, Shaders:162-181 */
+int fs_k_divergence(const fs_grid *g, const float *u, const float *v, float *div, void *stream);
+
+/* replaces kernel pressureSolve, Shaders:193-214, one sweep */
+int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream);
+
+/* n sweeps of pressureSolve, temporally blocked (the loop of Solver:533-541).
+ * If p_is_zero != 0 the contents of pa are ignored and taken as 0, which folds the
+ * clearTexture dispatch of Solver:528-530 into the first sweep.  Ping-pongs pa/pb. */
+int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *pb, int n,
+                         int p_is_zero, int *result_in_b, void *stream);
+
+/* replaces kernel subtractGradient, Shaders:225-245 (velocity in place) */
+int fs_k_subtractGradient(const fs_grid *g, const float *p, float *u, float *v, void *stream);
+
+/* replaces kernel calculateVorticity, Shaders:256-275 */
+int fs_k_calculateVorticity(const fs_grid *g, const float *u, const float *v, float *vort, void *stream);
+
+/* replaces kernel applyVorticity, Shaders:288-316 (buffer 0 strength, 1 deltaTime) */
+int fs_k_applyVorticity(const fs_grid *g, const float *vort, float *u, float *v,
+                        float strength, float deltaTime, void *stream);
+
+/* replaces kernel fadeDensity, Shaders:326-334 (buffer 0 fadeRate) */
+int fs_k_fadeDensity(const fs_grid *g, float *d, int nplanes, size_t plane_stride,
+                     float fadeRate, void *stream);
+
+/* replaces kernel clearTexture, Shaders:343-346 */
+int fs_k_clear(const fs_grid *g, float *t, int nplanes, size_t plane_stride, void *stream);
+
+/* replace kernels renderDensity / renderVelocity / renderSpeed, Shaders:357-414.
+ * out4 = 4 planes (R,G,B,A) with stride out_stride. */
+int fs_k_renderDensity(const fs_grid *g, const float *d, size_t d_stride, int d_planes,
+                       float *out4, size_t out_stride, float brightness, void *stream);
+int fs_k_renderVelocity(const fs_grid *g, const float *u, const float *v,
+                        float *out4, size_t out_stride, float scale, void *stream);
+int fs_k_renderSpeed(const fs_grid *g, const float *u, const float *v,
+                     float *out4, size_t out_stride, float scale, void *stream);
+
+/* Tracer parameters: the @Published scalars of Part:63-111 that update() reads,
+ * the solver viscosity it reads at Part:265 and its windowSize argument (Part:242). */
+typedef struct fs_particle_params {
+    float momentum;         /* Part:63,  default 0.5 */
+    float fluidForce;       /* Part:70,  default 0.6 */
+    float fluidDecayRate;   /* Part:98,  default 3.0 */
+    int   linkToViscosity;  /* Part:104, default 1   */
+    float viscosity;        /* FluidSolver.viscosity, Part:265 */
+    float windowW, windowH; /* windowSize of Part:242; tracer positions are in window units */
+} fs_particle_params;
+
+/* replaces the CPU loop ParticleSystem.update(), Part:242-304, with the velocity
+ * query of FluidSolver.getVelocityAt, Solver:648-663, done for real on the device
+ * field (nearest cell, real grid size; fluidVel = cell velocity / (W,H)).  SoA, in
+ * place.  Slots with life == 0 are dead and skipped; a particle that dies keeps its
+ * updated position and gets life = 0 (the reference removes it, Part:296). */
+int fs_k_particles_update(const fs_grid *g, const float *u, const float *v,
+                          const fs_particle_params *pp, long n,
+                          float *px, float *py, float *vx, float *vy,
+                          float *life, const float *mass, float *age, void *stream);
+
+/* No counterpart in the reference (it has one GPU and no CFL logic): max |plane| over
+ * rows [yb,ye), written as a float into *out_dev (device; must hold 0.0f beforehand).
+ * Used to size the advection halo of a row slab: ceil(max|v_y| * dt) + 1 rows. */
+int fs_k_max_abs(const fs_grid *g, const float *plane, float *out_dev, void *stream);
+
+/* -------------------------------------------------------------------------
+ * Layer 2: solver context (mirrors class FluidSolver, Solver:240-632, and the
+ * update half of class ParticleSystem, Part:242-304).
+ * ---------------------------------------------------------------------- */
+typedef struct fs_ctx fs_ctx;
+
+/* The @Published parameters update() reads (Solver:139-202, :227). */
+typedef struct fs_params {
+    float viscosity;         /* Solver:139 default 0.00015; diffuse runs iff > 0 (:505) */
+    float diffusion;         /* Solver:146 default 0.0;     dye diffuse runs iff > 0 (:562) */
+    float deltaTime;         /* Solver:153 default 0.5  */
+    float vorticityStrength; /* Solver:160 default 0.0;     confinement runs iff > 0 (:486) */
+    float fadeSpeed;         /* Solver:167 default 0.002 */
+    int   solverIterations;  /* Solver:174 default 10   */
+    int   displayMode;       /* Solver:214-225, FS_DISPLAY_*; FS_DISPLAY_NONE skips the render */
+    float brightness;        /* Solver:195 default 0.06 */
+} fs_params;
+
+enum { FS_DISPLAY_NONE = -1, FS_DISPLAY_DENSITY = 0, FS_DISPLAY_VELOCITY = 1, FS_DISPLAY_SPEED = 2,
+       FS_DISPLAY_VORTICITY = 3, FS_DISPLAY_PARTICLES_ONLY = 4 };
+
+enum { FS_FIELD_VELOCITY = 0, FS_FIELD_DENSITY = 1, FS_FIELD_PRESSURE = 2,
+       FS_FIELD_DIVERGENCE = 3, FS_FIELD_VORTICITY = 4, FS_FIELD_DISPLAY = 5 };
+
+/* options for fs_set_option */
+enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph */
+       FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), default 8 */
+       FS_OPT_WITH_PARTICLES = 2  /* 1: fs_step also runs the tracer update (default 0) */ };
+
+/* FluidSolver.init() + setResolution (Solver:240-255, :322-343): allocates the fields
+ * of a width x height grid on HIP device `device`, all zero (clearTextures :348-366). */
+int fs_create(int width, int height, int device, long max_particles, fs_ctx **out);
+int fs_destroy(fs_ctx *ctx);
+int fs_reset(fs_ctx *ctx);                                   /* reset(), Solver:371-374 */
+int fs_default_params(fs_params *p);                         /* defaults of Solver:139-202 */
+int fs_set_params(fs_ctx *ctx, const fs_params *p);
+int fs_get_params(fs_ctx *ctx, fs_params *p);
+int fs_set_option(fs_ctx *ctx, int option, int value);
+
+/* applyForce(position:force:color:), Solver:444-470, in GRID units (the 5 addForces
+ * arguments; color alpha is accepted for signature parity and ignored). */
+int fs_add_force(fs_ctx *ctx, float pos_x, float pos_y, float force_x, float force_y,
+                 const float color_rgba[4], float radius, float deltaTime);
+
+int fs_step(fs_ctx *ctx);   /* update(), Solver:477-627 */
+int fs_sync(fs_ctx *ctx);   /* wait for all queued work; reports a pending FS_ERR_HALO etc. */
+
+/* Host <-> device copies of a whole field, dense planar [plane][height][width] fp32.
+ * These double as checkpoint/restore and as the parity tap.  Blocking. */
+int fs_read_field(fs_ctx *ctx, int field, float *host, size_t bytes);
+int fs_write_field(fs_ctx *ctx, int field, const float *host, size_t bytes);
+
+/* Zero-copy view for hosts that already live on the device (benchmarks, torch):
+ * device pointer of plane `plane` of the field's CURRENT ping-pong side. */
+int fs_field_device_ptr(fs_ctx *ctx, int field, int plane, void **dev_ptr, int *pitch);
+void *fs_stream(fs_ctx *ctx);
+
+/* run one stage of update() on the context's own fields (n = sweeps for the two loops) */
+enum { FS_STAGE_VORTICITY = 0, FS_STAGE_APPLY_VORTICITY, FS_STAGE_DIFFUSE_VELOCITY, FS_STAGE_DIVERGENCE,
+       FS_STAGE_CLEAR_PRESSURE, FS_STAGE_PRESSURE, FS_STAGE_SUBTRACT_GRADIENT, FS_STAGE_ADVECT_VELOCITY,
+       FS_STAGE_DIFFUSE_DENSITY, FS_STAGE_ADVECT_DENSITY, FS_STAGE_FADE, FS_STAGE_RENDER };
+int fs_stage(fs_ctx *ctx, int stage, int n);
+
+/* Tracers (SoA on the device, owned by the context). */
+int fs_particles_set(fs_ctx *ctx, long n, const float *px, const float *py, const float *vx,
+                     const float *vy, const float *life, const float *mass, const float *age);
+int fs_particles_get(fs_ctx *ctx, long n, float *px, float *py, float *vx, float *vy,
+                     float *life, float *mass, float *age);
+int fs_default_particle_params(fs_particle_params *pp, float windowW, float windowH);
+int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
+long fs_particles_count(fs_ctx *ctx);
+
+const char *fs_last_error(fs_ctx *ctx); /* ctx may be NULL: last error of the calling thread */
+const char *fs_version(void);
+
+/* Harness helper (host code, no GPU): xorshift32 stream -> U[lo,hi) fp32, the
+ * generator SURVEY.md 8(d) names for synthetic inputs. */
+int fs_harness_fill_uniform(float *host_dst, long n, float lo, float hi, unsigned seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDSOLVER_H */

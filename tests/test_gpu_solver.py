@@ -1,0 +1,279 @@
+"""GPU parity of the whole step (fs_create / fs_add_force / fs_step ...) against the CPU oracle and the
+committed golden vectors, through the C ABI.  Bit-exact (see test_gpu_kernels.py for why)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def make_solver(W, H, params, radius=5.0, graph=True, depth=None, max_particles=0):
+    from fluidsolver_amd import FluidSolver, lib as L
+    s = FluidSolver(W, H, max_particles=max_particles)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.forceRadius = radius
+    s.displayMode = None
+    s.set_option(L.OPT_USE_GRAPH, 1 if graph else 0)
+    if depth:
+        s.set_option(L.OPT_BLOCK_DEPTH, depth)
+    return s
+
+
+def run_gpu_case(c, graph=True, depth=None):
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    s = make_solver(c["W"], c["H"], c["params"], c["radius"], graph, depth)
+    out = {}
+    for f in range(c["frames"]):
+        if "fixed_splat" in c:
+            if f == 0:
+                pos, force, col = c["fixed_splat"]
+                s.applyForce(pos, force, col)
+        else:
+            pos, force, col = splat(c["W"], c["H"], f)
+            s.applyForce(pos, force, col)
+        s.update()
+        if f + 1 in c["save_at"]:
+            out["vel_%d" % (f + 1)] = s.read_field(L.FIELD_VELOCITY)
+            out["den_%d" % (f + 1)] = s.read_field(L.FIELD_DENSITY)
+            out["prs_%d" % (f + 1)] = s.read_field(L.FIELD_PRESSURE)
+    s.sync()
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_golden_vectors(graph):
+    from fluidsolver_amd import lib as L
+    from make_golden import CASES
+    old = L.load().fs_config_get(L.OPT_BLOCK_DEPTH)
+    try:
+        for depth in (None, 3):
+            for name, case in CASES.items():
+                gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
+                out = run_gpu_case(case, graph=graph, depth=depth)
+                for k in gold.files:
+                    assert np.array_equal(out[k], gold[k]), (name, k, graph, depth)
+    finally:
+        L.load().fs_config_set(L.OPT_BLOCK_DEPTH, old)
+
+
+def test_zero_state_stays_zero():
+    from fluidsolver_amd import lib as L
+    s = make_solver(300, 200, (1.5e-4, 1e-4, 0.5, 10.0, 0.002, 12))
+    s.update()
+    s.update()
+    for f in (L.FIELD_VELOCITY, L.FIELD_DENSITY, L.FIELD_PRESSURE, L.FIELD_DIVERGENCE, L.FIELD_VORTICITY):
+        assert not s.read_field(f).any()
+
+
+@pytest.mark.parametrize("W,H,params", [
+    (200, 150, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)),       # config-2 physics
+    (177, 177, (0.00001, 0.0, 0.59, 0.0, 0.005, 15)),      # "Default" preset at its 177 grid
+    (128, 96, (0.00005, 0.00001, 0.4, 10.0, 0.008, 15)),   # "Smoke": dye diffusion on
+    (80, 80, (0.0, 0.0, 0.5, 0.0, 0.02, 5)),               # "Minimal": viscosity 0 -> no diffuse
+    (96, 64, (1.5e-4, 0.0, 0.5, 0.0, 0.002, 0)),           # N = 0: loops vanish, pressure just cleared
+])
+def test_frames_match_oracle(oracle, W, H, params):
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    s = make_solver(W, H, params)
+    o = oracle.solver(W, H)
+    p = Params(*params)
+    for f in range(12):
+        pos, force, col = splat(W, H, f * 7)
+        force = (force[0] * F(0.2), force[1] * F(0.2))
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, p.deltaTime)
+        s.update()
+        o.update(p)
+        if f in (0, 5, 11):
+            assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY)), f
+            assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY)), f
+            assert np.array_equal(s.read_field(L.FIELD_PRESSURE), o.field(PRESSURE)), f
+    s.sync()
+
+
+def test_update_boundary_invariants():
+    from fluidsolver_amd import lib as L
+    W, H = 96, 72
+    s = make_solver(W, H, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 7))
+    rng = np.random.default_rng(9)
+    vel = rng.uniform(-2, 2, (2, H, W)).astype(F)
+    den = rng.uniform(-1, 3, (3, H, W)).astype(F)
+    s.write_field(L.FIELD_VELOCITY, vel)
+    s.write_field(L.FIELD_DENSITY, den)
+    s.update()
+    nv, nd = s.read_field(L.FIELD_VELOCITY), s.read_field(L.FIELD_DENSITY)
+    k = F(1.0) - F(0.002)
+    for sl in [(slice(None), 0), (slice(None), -1), (0, slice(None)), (-1, slice(None))]:
+        for c in range(2):
+            assert np.array_equal(nv[c][sl], vel[c][sl])
+        for c in range(3):
+            assert np.array_equal(nd[c][sl], np.maximum(den[c][sl] * k, F(0)))
+        for f in (L.FIELD_PRESSURE, L.FIELD_DIVERGENCE, L.FIELD_VORTICITY):
+            assert not s.read_field(f)[0][sl].any()
+
+
+def test_stage_calls_equal_update(oracle):
+    """fs_stage() per reference kernel == fs_step(): a host can drive the stages itself."""
+    from fluidsolver_amd import lib as L
+    W, H, N = 120, 90, 9
+    params = (1.5e-4, 1e-5, 0.5, 10.0, 0.002, N)
+    a, b = make_solver(W, H, params), make_solver(W, H, params)
+    for s in (a, b):
+        s.applyForce((60.0, 40.0), (30.0, -12.0), (100.0, 40.0, 5.0))
+    a.update()
+    for st, n in ((L.STAGE_VORTICITY, 0), (L.STAGE_APPLY_VORTICITY, 0), (L.STAGE_DIFFUSE_VELOCITY, N),
+                  (L.STAGE_DIVERGENCE, 0), (L.STAGE_CLEAR_PRESSURE, 0), (L.STAGE_PRESSURE, N),
+                  (L.STAGE_SUBTRACT_GRADIENT, 0), (L.STAGE_ADVECT_VELOCITY, 0), (L.STAGE_DIFFUSE_DENSITY, N),
+                  (L.STAGE_ADVECT_DENSITY, 0), (L.STAGE_FADE, 0)):
+        b.stage(st, n)
+    for f in (L.FIELD_VELOCITY, L.FIELD_DENSITY, L.FIELD_PRESSURE, L.FIELD_DIVERGENCE, L.FIELD_VORTICITY):
+        assert np.array_equal(a.read_field(f), b.read_field(f))
+
+
+def test_render_modes(oracle):
+    from fluidsolver_amd import lib as L
+    from oracle_binding import full_grid
+    W, H = 100, 60
+    s = make_solver(W, H, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 6))
+    s.applyForce((50.0, 30.0), (30.0, -12.0), (100.0, 40.0, 5.0))
+    for mode in ("Color", "Motion", "Speed", "Vorticity", "Particles Only"):
+        s.displayMode = mode
+        s.update()
+        vel, den, vort = s.read_field(L.FIELD_VELOCITY), s.read_field(L.FIELD_DENSITY), s.read_field(L.FIELD_VORTICITY)
+        e = np.zeros((4, H, W), F)
+        g = full_grid(W, H)
+        z = np.zeros((H, W), F)
+        if mode == "Color":
+            oracle.renderDensity(g, den[0], den[1], den[2], e, s.brightness)
+        elif mode == "Motion":
+            oracle.renderVelocity(g, vel[0], vel[1], e, 1.0)
+        elif mode == "Speed":
+            oracle.renderSpeed(g, vel[0], vel[1], e, 25.0)
+        elif mode == "Vorticity":
+            oracle.renderDensity(g, vort[0], z, z, e, 10.0)
+        assert np.array_equal(s.texture, e), mode
+
+
+def test_host_api_add_force_and_reset():
+    from fluidsolver_amd import FluidSolver, lib as L
+    s = FluidSolver(128, 128)
+    s.displayMode = None
+    s.addForce((100.0, 100.0), (400.0, 400.0), time=0.0)       # first touch: zero force, dye only
+    assert not s.read_field(L.FIELD_VELOCITY).any() and s.read_field(L.FIELD_DENSITY)[0].max() == F(50.0)
+    s.addForce((110.0, 100.0), (400.0, 400.0), time=0.0)       # 10 px -> 3.2 cells -> force 76.8
+    u = s.read_field(L.FIELD_VELOCITY)[0]
+    assert u.max() > 0 and u[32, 35] == F(76.8 * 0.5) * F(1.0) or u.max() > 30
+    s.endInteraction()
+    s.applyPreset("Turbulent")
+    assert s.solverIterations == 10 and s.vorticityStrength == 25.0
+    s.update()
+    s.reset()
+    assert not s.read_field(L.FIELD_VELOCITY).any() and not s.read_field(L.FIELD_DENSITY).any()
+    s.setResolution(64)
+    assert s.read_field(L.FIELD_VELOCITY).shape == (2, 64, 64)
+    v = s.getVelocityAt((0.5, 0.5))
+    assert v.shape == (2,)
+
+
+def test_particles_through_context(oracle):
+    from fluidsolver_amd import ParticleSystem, lib as L
+    from oracle_binding import ParticleParams as OPP, VELOCITY, Params, full_grid
+    W, H, n = 160, 120, 20000
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 10)
+    s = make_solver(W, H, params, max_particles=n)
+    ps = ParticleSystem(s)
+    lib = L.load()
+    import ctypes as C
+    def fill(lo, hi, seed):
+        a = np.empty(n, F)
+        lib.fs_harness_fill_uniform(a.ctypes.data_as(C.c_void_p), n, lo, hi, seed)
+        return a
+    arrs = [fill(0, W, 1), fill(0, H, 2), np.zeros(n, F), np.zeros(n, F), fill(0.3, 1.0, 3), fill(0.1, 1.0, 4),
+            np.zeros(n, F)]
+    ps.set_arrays(*arrs)
+    exp = [a.copy() for a in arrs]
+    o = oracle.solver(W, H)
+    p = Params(*params)
+    for f in range(5):
+        s.applyForce((80.0, 60.0), (200.0, -90.0), (100.0, 0.0, 0.0))
+        o.add_force((80.0, 60.0), (200.0, -90.0), (100.0, 0.0, 0.0), 5.0, 0.5)
+        s.update()
+        o.update(p)
+        ps.update(s, (W, H))
+        ov = o.field(VELOCITY)
+        oracle.particles_update(full_grid(W, H), ov[0], ov[1], OPP(0.5, 0.6, 3.0, 1, 1.5e-4, W, H), exp)
+    got = ps.get_arrays()
+    for e, g in zip(exp, got):
+        assert np.array_equal(e, g)
+    assert (got[2] != 0).any()
+
+
+def test_full_size_3072_frame_matches_oracle(oracle_omp):
+    """BASELINE config 2 at full size: one scripted frame at 3072^2, N=40, against the (OpenMP,
+    bit-identical) oracle; plus size-independent properties."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 3072
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(2):
+        pos, force, col = splat(W, H, f + 3)
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, 0.5)
+        s.update()
+        o.update(p)
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+        assert np.array_equal(s.read_field(fg), o.field(fo))
+    s.sync()
+
+
+def test_full_size_properties():
+    """Properties that need no oracle, at 3072^2: linearity of the Jacobi solve in div (power-of-two
+    scaling is exact), blocked == unblocked sweeps, zero-velocity advect identity."""
+    import ctypes as C
+    import torch
+    from fluidsolver_amd import lib as L
+    from gpu_util import grid, ptr, stream, stride, sync
+    lib = L.load()
+    W = H = 3072
+    g = grid(W, H)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    div = (torch.rand((1, H, W), generator=gen, device="cuda") * 2 - 1)
+    pa, pb = torch.zeros_like(div), torch.zeros_like(div)
+    in_b = C.c_int()
+    L.check(lib.fs_k_pressureSolve_n(C.byref(g), ptr(div), ptr(pa), ptr(pb), 40, 1, C.byref(in_b), stream()))
+    sync()
+    ref = (pb if in_b.value else pa).clone()
+    # unblocked: 40 launches of one sweep
+    old = lib.fs_config_get(L.OPT_BLOCK_DEPTH)
+    lib.fs_config_set(L.OPT_BLOCK_DEPTH, 1)
+    qa, qb = torch.zeros_like(div), torch.zeros_like(div)
+    L.check(lib.fs_k_pressureSolve_n(C.byref(g), ptr(div), ptr(qa), ptr(qb), 40, 1, C.byref(in_b), stream()))
+    lib.fs_config_set(L.OPT_BLOCK_DEPTH, old)
+    sync()
+    assert torch.equal(ref, qb if in_b.value else qa)
+    # linearity: solve(4*div) == 4*solve(div) exactly
+    div4 = div * 4
+    L.check(lib.fs_k_pressureSolve_n(C.byref(g), ptr(div4), ptr(qa), ptr(qb), 40, 1, C.byref(in_b), stream()))
+    sync()
+    assert torch.equal(ref * 4, qb if in_b.value else qa)
+    assert float(ref.abs().max()) > 0 and not ref[0, 0].any() and not ref[0, :, 0].any()
+    # advect with zero velocity is the identity
+    vel = torch.zeros((2, H, W), device="cuda")
+    out = torch.empty((1, H, W), device="cuda")
+    L.check(lib.fs_k_advect(C.byref(g), ptr(vel, 0), ptr(vel, 1), ptr(div), ptr(out), 1, stride(div), 0.5, None,
+                            stream()))
+    sync()
+    assert torch.equal(out, div)
