@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the stable-fluids step on MI355X (driver contract: see README/DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config5]
+
+A "step" is one frame: one scripted splat + FluidSolver.update() (+ the tracer
+update for config3).  N = 1 runs the workload on one GPU through the solver context (hipGraph);
+N > 1 (launched by torch.distributed.run, one rank per GPU) runs row slabs with halo exchange over
+RCCL.  Rank 0 prints ONE JSON line.
+
+value = cells x frames/s / 1e9 (Gcell-updates/s of whole frames), inputs resident in HBM.
+roofline = the pressure Jacobi kernel (k_jacobi_block<pressure>), effective bandwidth =
+ALGORITHMIC bytes (12 B/cell/sweep) / launch time measured with HIP events.
+cpu_baseline = the scalar CPU oracle (oracle/) timed on this host on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X nominal HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+ALG_BYTES_PRESSURE_SWEEP = 12   # read div 4 + read p 4 + write p 4
+# full frame, config 2: 12 + 20 + 40*16 + 12 + 4 + 40*12 + 20 + 16 + 32 + 24
+ALG_BYTES_FRAME_CONFIG2 = 1260
+
+WORKLOADS = {
+    # name: (W, H per GPU or total, params(visc, diff, dt, vort, fade, N), particles, scaling)
+    "config2": dict(W=3072, H=3072, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=0, scaling="weak",
+                    desc="3072x3072 full step: vorticity + diffuse + 40 pressure iters + RGB dye advect"),
+    "config3": dict(W=3072, H=3072, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=1 << 20, scaling="weak",
+                    desc="config2 + 1,048,576 tracer particles"),
+    "config4": dict(W=16384, H=16384, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=0, scaling="strong",
+                    desc="16384x16384 full step, row slabs, strong scaling"),
+    "config5": dict(W=8192, H=8192, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 100), particles=0, scaling="weak",
+                    desc="8192x8192 per GPU, 100 pressure iters, weak scaling"),
+}
+
+
+def make_single(W, H, params, particles):
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    s = FluidSolver(W, H, max_particles=particles)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None   # headless: the render pass is a "next" row, not part of the sim
+    ps = None
+    if particles:
+        lib = L.load()
+        ps = ParticleSystem(s)
+
+        def fill(lo, hi, seed):
+            a = np.empty(particles, np.float32)
+            lib.fs_harness_fill_uniform(a.ctypes.data_as(C.c_void_p), particles, lo, hi, seed)
+            return a
+        z = np.zeros(particles, np.float32)
+        # xorshift32 seed 0x9E3779B9, positions uniform over the grid,
+        # mass ~ U(0.1,1), life ~ U(0.3,1), age = 0
+        ps.set_arrays(fill(0, W, 0x9E3779B9), fill(0, H, 0x9E3779B9 ^ 1), z, z, fill(0.3, 1.0, 0x9E3779B9 ^ 2),
+                      fill(0.1, 1.0, 0x9E3779B9 ^ 3), z)
+    return s, ps
+
+
+def frame_single(s, ps, f, W, H):
+    from fluidsolver_amd.script import splat
+    pos, force, col = splat(W, H, f)
+    s.applyForce(pos, force, col)
+    s.update()
+    if ps is not None:
+        ps.update(s, (W, H))
+
+
+def jacobi_microbench(s, W, H, sweeps=40, reps=10):
+    """SURVEY 8(d) Jacobi micro-benchmark: pressureSolve alone on div ~ U(-1,1) (xorshift32 seed 1234),
+    HIP-event timed on the context's stream.  Returns (ms per launch, sweeps per launch, ms per sweep)."""
+    from fluidsolver_amd import lib as L
+    lib = L.load()
+    div = np.empty((1, H, W), np.float32)
+    lib.fs_harness_fill_uniform(div.ctypes.data_as(C.c_void_p), div.size, -1.0, 1.0, 1234)
+    s.write_field(L.FIELD_DIVERGENCE, div)
+    s.write_field(L.FIELD_PRESSURE, np.zeros((1, H, W), np.float32))
+    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH)
+    s.stage(L.STAGE_PRESSURE, sweeps)   # warm-up
+    s.sync()
+    ms = C.c_float()
+    L.check(lib.fs_timer_begin(s.ctx), s.ctx)
+    for _ in range(reps):
+        L.check(lib.fs_stage(s.ctx, L.STAGE_PRESSURE, sweeps), s.ctx)
+    L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
+    launches = reps * ((sweeps + depth - 1) // depth)
+    return ms.value / launches, sweeps * reps / launches, ms.value / (reps * sweeps)
+
+
+def cpu_baseline(W, H, params, budget_s=20.0):
+    """The scalar oracle ("port", 1 thread) on a bounded sample of the same workload: whole frames of
+    the same scripted input, as many as fit the budget (at least 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle, Params
+    from fluidsolver_amd.script import splat
+    o = Oracle(omp=False)
+    s = o.solver(W, H)
+    p = Params(*params)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        pos, force, col = splat(W, H, frames)
+        s.add_force(pos, force, col, 5.0, p.deltaTime)
+        s.update(p)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or el * (frames + 1) / frames > budget_s * 1.5:
+            break
+    fps = frames / el
+    return dict(value=W * H * fps / 1e9, unit="Gcell-updates/s", cores=1, kind="port",
+                sample="%d whole frame(s) of the same %dx%d scripted workload, scalar C oracle (gcc -O2 "
+                       "-ffp-contract=off), %.1f s" % (frames, W, H, el),
+                frames_per_s=fps, host_cpus=os.cpu_count())
+
+
+def load_traffic():
+    """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/), if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("k_jacobi_block_pressure_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="Jacobi temporal-blocking depth (0 = library default)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+
+    from fluidsolver_amd import lib as L
+    lib = L.load()
+    if args.depth:
+        L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH, args.depth))
+    wl = WORKLOADS[args.workload]
+    W, Hg = wl["W"], wl["H"]
+    params = wl["params"]
+
+    if world == 1:
+        H = Hg
+        s, ps = make_single(W, H, params, wl["particles"])
+        step = lambda f: frame_single(s, ps, f, W, H)   # noqa: E731
+        barrier = lambda: None                          # noqa: E731
+        sync_all = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
+        total_cells = W * H
+        parallelism = "1 GPU"
+    else:
+        import torch.distributed as dist
+        from fluidsolver_amd.slabs import SlabSolver
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        H = Hg * world if wl["scaling"] == "weak" else Hg
+        s = SlabSolver(W, H, params, device=local_rank)
+        n_ptr = world
+        step = lambda f: s.frame(f, n_pointers=n_ptr)   # noqa: E731
+        barrier = dist.barrier
+        sync_all = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
+        total_cells = W * H
+        parallelism = "%d row slabs (RCCL halo exchange)" % world
+
+    for f in range(args.warmup):
+        step(f)
+    sync_all()
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        step(f)
+    sync_all()
+    barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    fps = args.steps / elapsed
+    out = {
+        "metric": "Gcell-updates/s, full stable-fluids step (cells x frames/s); frames/s and Jacobi "
+                  "Gcell-updates/s per sweep alongside",
+        "value": total_cells * fps / 1e9,
+        "unit": "Gcell-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": wl["scaling"],
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (scripted Lissajous splats, SURVEY 8(d); zero initial state)",
+        "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "grid": [W, H],
+                   "solverIterations": params[5], "particles": wl["particles"], "parallelism": parallelism,
+                   "jacobi_block_depth": lib.fs_config_get(L.OPT_BLOCK_DEPTH)},
+        "frames_per_s": fps,
+    }
+
+    if world == 1:
+        alg = ALG_BYTES_FRAME_CONFIG2 if params[5] == 40 else None
+        if alg:
+            out["frame_effective_GBps"] = alg * total_cells * fps / 1e9
+            out["frame_frac_hbm_peak"] = out["frame_effective_GBps"] / HBM_PEAK_GBS
+        ms_launch, sweeps_per_launch, ms_sweep = jacobi_microbench(s, W, H)
+        achieved = ALG_BYTES_PRESSURE_SWEEP * total_cells * sweeps_per_launch / (ms_launch * 1e-3) / 1e9
+        out["jacobi"] = {"gcell_updates_per_s_per_sweep": total_cells / (ms_sweep * 1e-3) / 1e9,
+                         "us_per_sweep": ms_sweep * 1e3, "us_per_launch": ms_launch * 1e3,
+                         "sweeps_per_launch": sweeps_per_launch}
+        out["roofline"] = {"kernel": "k_jacobi_block<pressure> (%g sweeps/launch)" % sweeps_per_launch,
+                           "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                           "note": "achieved = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
+                                   "HIP-event launch time; temporal blocking keeps T sweeps on chip, so the "
+                                   "effective figure may exceed the HBM peak"}
+        if not args.no_cpu_baseline and rank == 0:
+            out["cpu_baseline"] = cpu_baseline(W, H, params)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,7 @@ struct fs_ctx {
     long max_particles = 0, n_particles = 0;
     float *part[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     fs_particle_params pparams{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
     char error[512] = "";
 };
 
@@ -109,7 +110,7 @@ static int ctx_fail(fs_ctx *c, int rc)
 
 static void drop_graphs(fs_ctx *c)
 {
-    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graphs_after.clear();
 }
@@ -343,13 +344,15 @@ int fs_create(int width, int height, int device, long max_particles, fs_ctx **ou
 int fs_destroy(fs_ctx *c)
 {
     if (!c) return FS_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graphs(c);
-    for (int i = 0; i < 2; ++i) { hipFree(c->vel[i]); hipFree(c->den[i]); hipFree(c->prs[i]); }
-    hipFree(c->div); hipFree(c->vort); hipFree(c->display); hipFree(c->err_flag);
-    for (int i = 0; i < 7; ++i) hipFree(c->part[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(c->vel[i]); (void)hipFree(c->den[i]); (void)hipFree(c->prs[i]); }
+    (void)hipFree(c->div); (void)hipFree(c->vort); (void)hipFree(c->display); (void)hipFree(c->err_flag);
+    for (int i = 0; i < 7; ++i) (void)hipFree(c->part[i]);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FS_OK;
 }
@@ -442,14 +445,14 @@ int fs_step(fs_ctx *c)
         int rc = enqueue_update(c);
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc || e != hipSuccess) {
-            if (graph) hipGraphDestroy(graph);
+            if (graph) (void)hipGraphDestroy(graph);
             c->vcur = v0; c->dcur = d0; c->pcur = p0;
             if (rc) return ctx_fail(c, rc);
             return ctx_fail(c, fs::hip_fail(e, "hipStreamEndCapture"));
         }
         hipGraphExec_t exec = nullptr;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
             c->vcur = v0; c->dcur = d0; c->pcur = p0;
             return ctx_fail(c, fs::hip_fail(e, "hipGraphInstantiate"));
@@ -475,7 +478,7 @@ int fs_sync(fs_ctx *c)
     int flag = 0;
     TRYHIP(c, hipMemcpy(&flag, c->err_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
-        hipMemset(c->err_flag, 0, sizeof(int));
+        (void)hipMemset(c->err_flag, 0, sizeof(int));
         fs::set_error("advect backtrace left the buffered rows (halo too small)");
         return ctx_fail(c, FS_ERR_HALO);
     }
@@ -525,6 +528,24 @@ int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pi
 }
 
 void *fs_stream(fs_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int fs_timer_begin(fs_ctx *c)
+{
+    CTX(c);
+    if (!c->ev0) { TRYHIP(c, hipEventCreate(&c->ev0)); TRYHIP(c, hipEventCreate(&c->ev1)); }
+    TRYHIP(c, hipEventRecord(c->ev0, c->stream));
+    return FS_OK;
+}
+
+int fs_timer_end(fs_ctx *c, float *ms)
+{
+    CTX(c);
+    if (!c->ev0 || !ms) { fs::set_error("fs_timer_end without fs_timer_begin"); return ctx_fail(c, FS_ERR_STATE); }
+    TRYHIP(c, hipEventRecord(c->ev1, c->stream));
+    TRYHIP(c, hipEventSynchronize(c->ev1));
+    TRYHIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return FS_OK;
+}
 
 int fs_stage(fs_ctx *c, int stage, int n)
 {

@@ -87,6 +87,8 @@ SIGNATURES = {
     "fs_write_field": (_i, [_p, _i, _p, _sz]),
     "fs_field_device_ptr": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i)]),
     "fs_stream": (_p, [_p]),
+    "fs_timer_begin": (_i, [_p]),
+    "fs_timer_end": (_i, [_p, C.POINTER(_f)]),
     "fs_stage": (_i, [_p, _i, _i]),
     "fs_particles_set": (_i, [_p, _l] + [_p] * 7),
     "fs_particles_get": (_i, [_p, _l] + [_p] * 7),

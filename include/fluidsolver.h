@@ -225,6 +225,11 @@ int fs_write_field(fs_ctx *ctx, int field, const float *host, size_t bytes);
 int fs_field_device_ptr(fs_ctx *ctx, int field, int plane, void **dev_ptr, int *pitch);
 void *fs_stream(fs_ctx *ctx);
 
+/* HIP-event stopwatch on the context's stream (benchmarks): begin records an event, end records a
+ * second one, waits for it and returns the elapsed milliseconds of the work queued in between. */
+int fs_timer_begin(fs_ctx *ctx);
+int fs_timer_end(fs_ctx *ctx, float *ms);
+
 /* run one stage of update() on the context's own fields (n = sweeps for the two loops) */
 enum { FS_STAGE_VORTICITY = 0, FS_STAGE_APPLY_VORTICITY, FS_STAGE_DIFFUSE_VELOCITY, FS_STAGE_DIVERGENCE,
        FS_STAGE_CLEAR_PRESSURE, FS_STAGE_PRESSURE, FS_STAGE_SUBTRACT_GRADIENT, FS_STAGE_ADVECT_VELOCITY,
