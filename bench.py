@@ -150,6 +150,8 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if os.environ.get("FS_BENCH_REHEARSAL") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from fluidsolver_amd import lib as L
@@ -171,9 +173,18 @@ def main():
     else:
         import torch.distributed as dist
         from fluidsolver_amd.slabs import SlabSolver
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # FS_BENCH_REHEARSAL=1: rehearse the multi-rank code path on a 1-GPU box (all ranks on cuda:0,
+        # halos staged through the host over gloo).  Never set by the driver; numbers are meaningless.
+        rehearsal = os.environ.get("FS_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            from fluidsolver_amd.slabs import Comm
+            dist.init_process_group("gloo")
+            comm = Comm(stage_through_host=True)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm = None
         H = Hg * world if wl["scaling"] == "weak" else Hg
-        s = SlabSolver(W, H, params, device=local_rank)
+        s = SlabSolver(W, H, params, device=local_rank, comm=comm)
         n_ptr = world
         step = lambda f: s.frame(f, n_pointers=n_ptr)   # noqa: E731
         barrier = dist.barrier
@@ -194,7 +205,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -236,6 +247,10 @@ def main():
                                    "effective figure may exceed the HBM peak"}
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
+    if world > 1:
+        out["slab"] = {"ghost_rows": s.G, "last_advect_halo": getattr(s, "last_halo", None),
+                       "exchange_rounds_per_frame": s.stats["exchanges"] / float(args.warmup + args.steps),
+                       "gathers": s.stats["gathers"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
