@@ -83,7 +83,7 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=10):
     lib.fs_harness_fill_uniform(div.ctypes.data_as(C.c_void_p), div.size, -1.0, 1.0, 1234)
     s.write_field(L.FIELD_DIVERGENCE, div)
     s.write_field(L.FIELD_PRESSURE, np.zeros((1, H, W), np.float32))
-    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH)
+    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE)
     s.stage(L.STAGE_PRESSURE, sweeps)   # warm-up
     s.sync()
     ms = C.c_float()
@@ -92,7 +92,7 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=10):
         L.check(lib.fs_stage(s.ctx, L.STAGE_PRESSURE, sweeps), s.ctx)
     L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
     launches = reps * ((sweeps + depth - 1) // depth)
-    return ms.value / launches, sweeps * reps / launches, ms.value / (reps * sweeps)
+    return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
 
 
 def cpu_baseline(W, H, params, budget_s=20.0):
@@ -225,7 +225,8 @@ def main():
         "data": "synthetic (scripted Lissajous splats, SURVEY 8(d); zero initial state)",
         "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "grid": [W, H],
                    "solverIterations": params[5], "particles": wl["particles"], "parallelism": parallelism,
-                   "jacobi_block_depth": lib.fs_config_get(L.OPT_BLOCK_DEPTH)},
+                   "jacobi_block_depth": {"pressure": lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE),
+                                          "diffuse": lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE)}},
         "frames_per_s": fps,
     }
 

@@ -11,8 +11,10 @@
 
 namespace fs {
 
-int config_set_block_depth(int v);
-int config_get_block_depth();
+int config_set_block_depth(int op, int v);
+int config_get_block_depth(int op);
+int config_set_tile_variant(int v);
+int config_get_tile_variant();
 
 static thread_local char tl_error[512] = "";
 
@@ -73,6 +75,7 @@ struct fs_ctx {
     unsigned params_version = 0;
     int use_graph = 1;
     int with_particles = 0;
+    int fuse = 1;
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
     std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
     // tracers
@@ -206,6 +209,14 @@ static int st_advect_density(fs_ctx *c)
     if (!rc) c->dcur ^= 1;                                                            // :584
     return rc;
 }
+static int st_advect_density_fade(fs_ctx *c)
+{
+    float *u = c->vel[c->vcur], *v = u + c->plane;
+    int rc = fs_k_advect_fade(&c->grid, u, v, c->den[c->dcur], c->den[c->dcur ^ 1], 3, c->plane,
+                              c->params.deltaTime, c->params.fadeSpeed, c->err_flag, c->stream);  // Solver:577-591
+    if (!rc) c->dcur ^= 1;
+    return rc;
+}
 static int st_fade(fs_ctx *c)
 {
     return fs_k_fadeDensity(&c->grid, c->den[c->dcur], 3, c->plane, c->params.fadeSpeed, c->stream);  // Solver:587-591
@@ -254,8 +265,12 @@ static int enqueue_update(fs_ctx *c)
     if (p.diffusion > 0.0f) {                                    // :562
         if ((rc = st_diffuse_density(c, N))) return rc;
     }
-    if ((rc = st_advect_density(c))) return rc;                  // :577-584
-    if ((rc = st_fade(c))) return rc;                            // :587
+    if (c->fuse) {
+        if ((rc = st_advect_density_fade(c))) return rc;         // :577-591 in one pass
+    } else {
+        if ((rc = st_advect_density(c))) return rc;              // :577-584
+        if ((rc = st_fade(c))) return rc;                        // :587
+    }
     if ((rc = st_render(c))) return rc;                          // :594-623
     if (c->with_particles && c->n_particles > 0) {
         if ((rc = st_particles(c))) return rc;                   // MetalView.swift:155 -> Part:242
@@ -404,9 +419,13 @@ int fs_set_option(fs_ctx *c, int option, int value)
     switch (option) {
     case FS_OPT_USE_GRAPH: c->use_graph = value ? 1 : 0; break;
     case FS_OPT_BLOCK_DEPTH:
-        if (fs::config_set_block_depth(value)) { fs::set_error("block depth %d out of range 1..24", value); return ctx_fail(c, FS_ERR_INVALID); }
+        if (fs::config_set_block_depth(-1, value)) { fs::set_error("block depth %d out of range 1..48", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
+    case FS_OPT_FUSE: c->fuse = value ? 1 : 0; break;
+    case FS_OPT_TILE_VARIANT:
+        if (fs::config_set_tile_variant(value)) { fs::set_error("tile variant %d out of range 0..5", value); return ctx_fail(c, FS_ERR_INVALID); }
+        break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     drop_graphs(c);
@@ -625,12 +644,17 @@ int fs_harness_fill_uniform(float *dst, long n, float lo, float hi, unsigned see
 
 int fs_config_set(int key, int value)
 {
-    if (key == FS_OPT_BLOCK_DEPTH) return fs::config_set_block_depth(value);
+    if (key == FS_OPT_BLOCK_DEPTH) return fs::config_set_block_depth(-1, value);
+    if (key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_set_block_depth(0, value);
+    if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_set_block_depth(1, value);
+    if (key == FS_OPT_TILE_VARIANT) return fs::config_set_tile_variant(value);
     return FS_ERR_INVALID;
 }
 int fs_config_get(int key)
 {
-    if (key == FS_OPT_BLOCK_DEPTH) return fs::config_get_block_depth();
+    if (key == FS_OPT_BLOCK_DEPTH || key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_get_block_depth(0);
+    if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_get_block_depth(1);
+    if (key == FS_OPT_TILE_VARIANT) return fs::config_get_tile_variant();
     return FS_ERR_INVALID;
 }
 

@@ -38,20 +38,76 @@ struct JacobiArgs {
     int T;             // sweeps in this launch (>= 1)
     int HX;            // horizontal halo, multiple of 4, >= T
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
+    double rden;       // RN64(1 / den)
 };
 
+// x / den for a launch-constant den, bit-identical to the IEEE fp32 division the reference formula
+// asks for, at 3 instructions instead of the ~12 of v_div_scale/v_rcp/fma.../v_div_fixup:
+//     q = RN32( RN64( (double)x * RN64(1/den) ) ).
+// Proof sketch: the fp64 product is within 2^-52 (relative) of the exact quotient x/den, while the exact
+// quotient of two fp32 numbers is never closer than 2^-49 (relative) to an fp32 rounding boundary
+// (midpoint of adjacent floats) and never on one; in the fp32-subnormal range the same holds in
+// absolute terms (2^-174 vs 2^-178).  So both round to the same fp32.  fp64 holds every fp32
+// (sub)normal exactly, so there are no special cases.  Checked exhaustively over all 2^32 x for a set
+// of den by fs_selftest_divide (tests/test_gpu_kernels.py).
+__device__ __forceinline__ float div_const(float x, double rden) { return (float)((double)x * rden); }
+
 template <int OP>
-__device__ __forceinline__ float sweep_cell(float c, float l, float r, float t, float b, float d, float a, float den)
+__device__ __forceinline__ float sweep_cell(float c, float l, float r, float t, float b, float d, float a, double rden)
 {
     if (OP == OP_PRESSURE) {
-        return ((((d + l) + r) + t) + b) / 4.0f;       // Shaders:212
+        return ((((d + l) + r) + t) + b) / 4.0f;                  // Shaders:212 (x/4 == x*0.25 exactly)
     } else {
-        return (c + a * (((l + r) + t) + b)) / den;    // Shaders:103
+        return div_const(c + a * (((l + r) + t) + b), rden);      // Shaders:103
     }
 }
 
-template <int OP, int R, int NW>
-__global__ __launch_bounds__(NW * 64) void k_jacobi_block(JacobiArgs A)
+// T sweeps on the register tile.  EDGE = the tile touches a fixed (boundary / outside) row or column;
+// interior tiles (the vast majority) run the lean instantiation with no selects at all.
+template <int OP, int R, int NW, bool EDGE>
+__device__ __forceinline__ void run_sweeps_tile(float4 (&p)[R], const float4 (&d)[R], float4 (*xch)[NW][2][64], int T,
+                                                int lane, int wave, unsigned rowfixed, bool fx0, bool fx1, bool fx2,
+                                                bool fx3, float a, double rden)
+{
+    const int wup = wave > 0 ? wave - 1 : 0;            // tile rim rows have no neighbour: any value, never used
+    const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
+    for (int s = 0; s < T; ++s) {
+        const int buf = s & 1;
+        xch[buf][wave][0][lane] = p[0];
+        xch[buf][wave][1][lane] = p[R - 1];
+        __syncthreads();
+        float4 prev = xch[buf][wup][1][lane];           // row above this wave's strip
+        const float4 below = xch[buf][wdn][0][lane];    // row below it
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float4 c = p[i];
+            const float4 nx = (i < R - 1) ? p[i + 1] : below;
+            const float l = from_lane_below(c.w);   // column 4l-1
+            const float r = from_lane_above(c.x);   // column 4l+4
+            float4 n;
+            n.x = sweep_cell<OP>(c.x, l, c.y, prev.x, nx.x, d[i].x, a, rden);
+            n.y = sweep_cell<OP>(c.y, c.x, c.z, prev.y, nx.y, d[i].y, a, rden);
+            n.z = sweep_cell<OP>(c.z, c.y, c.w, prev.z, nx.z, d[i].z, a, rden);
+            n.w = sweep_cell<OP>(c.w, c.z, r, prev.w, nx.w, d[i].w, a, rden);
+            if (EDGE) {
+                // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
+                const float4 fixedv = OP == OP_PRESSURE ? make_float4(0.f, 0.f, 0.f, 0.f) : c;
+                if (fx0) n.x = fixedv.x;
+                if (fx1) n.y = fixedv.y;
+                if (fx2) n.z = fixedv.z;
+                if (fx3) n.w = fixedv.w;
+                if ((rowfixed >> i) & 1u) n = fixedv;
+            }
+            p[i] = n;
+            prev = c;
+        }
+    }
+}
+
+// MINW = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
+// (8 rows, 8 waves) at MINW 4 keeps two 512-thread workgroups per CU, so one can load while the other sweeps.
+template <int OP, int R, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 {
     constexpr int TW = 256;
     constexpr int TH = NW * R;
@@ -76,8 +132,8 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_block(JacobiArgs A)
     const bool fx1 = (gx + 1) <= 0 || (gx + 1) >= g.W - 1;
     const bool fx2 = (gx + 2) <= 0 || (gx + 2) >= g.W - 1;
     const bool fx3 = (gx + 3) <= 0 || (gx + 3) >= g.W - 1;
-    // wave-uniform: does this tile touch a fixed column at all?
-    const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1;
+    // block-uniform: does this tile touch a fixed column or row at all?
+    const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1 || ry0 <= 0 || ry0 + TH >= g.H - 1;
 
     float4 p[R];
     float4 d[R];
@@ -99,38 +155,10 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_block(JacobiArgs A)
         d[i] = dv;
     }
 
-    for (int s = 0; s < A.T; ++s) {
-        const int buf = s & 1;
-        xch[buf][wave][0][lane] = p[0];
-        xch[buf][wave][1][lane] = p[R - 1];
-        __syncthreads();
-        // rows above / below this wave's strip (tile rim rows have no neighbour: any value, never used)
-        float4 prev = wave > 0 ? xch[buf][wave - 1][1][lane] : p[0];
-        const float4 below = wave < NW - 1 ? xch[buf][wave + 1][0][lane] : p[R - 1];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const float4 c = p[i];
-            const float4 nx = (i < R - 1) ? p[i + 1] : below;
-            const float l = from_lane_below(c.w);   // column 4l-1
-            const float r = from_lane_above(c.x);   // column 4l+4
-            float4 n;
-            n.x = sweep_cell<OP>(c.x, l, c.y, prev.x, nx.x, d[i].x, A.a, A.den);
-            n.y = sweep_cell<OP>(c.y, c.x, c.z, prev.y, nx.y, d[i].y, A.a, A.den);
-            n.z = sweep_cell<OP>(c.z, c.y, c.w, prev.z, nx.z, d[i].z, A.a, A.den);
-            n.w = sweep_cell<OP>(c.w, c.z, r, prev.w, nx.w, d[i].w, A.a, A.den);
-            // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
-            const float4 fixedv = OP == OP_PRESSURE ? make_float4(0.f, 0.f, 0.f, 0.f) : c;
-            if (edge_tile) {
-                if (fx0) n.x = fixedv.x;
-                if (fx1) n.y = fixedv.y;
-                if (fx2) n.z = fixedv.z;
-                if (fx3) n.w = fixedv.w;
-            }
-            if ((rowfixed >> i) & 1u) n = fixedv;
-            p[i] = n;
-            prev = c;
-        }
-    }
+    if (edge_tile)
+        run_sweeps_tile<OP, R, NW, true>(p, d, xch, A.T, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
+    else
+        run_sweeps_tile<OP, R, NW, false>(p, d, xch, A.T, lane, wave, 0u, false, false, false, false, A.a, A.rden);
 
     // store the exact inner region
     const bool col_out = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
@@ -145,13 +173,27 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_block(JacobiArgs A)
 }
 
 // tuning knobs (process-wide; see fs_config_set)
-static int g_block_depth = 8;
+// Depths from the 3072^2 sweep in profiles/r01_tune_jacobi.log: the pressure sweep is cheap per cell, so
+// fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
+static int g_block_depth[2] = {10, 8};   // [OP_PRESSURE], [OP_DIFFUSE]
+static int g_tile_variant = 0;   // index into the (R rows per lane, NW waves) table below
+
+template <int OP, int R, int NW, int MINW>
+static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, hipStream_t stream)
+{
+    JacobiArgs A = A0;
+    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * A.T;
+    if (OH < 1) { set_error("jacobi: block depth %d too deep for a %d-row tile", A.T, NW * R); return FS_ERR_INVALID; }
+    dim3 grid((g->width + OW - 1) / OW, (A.ye - A.yb + OH - 1) / OH, nplanes);
+    hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW>), grid, dim3(NW * 64), 0, stream, A);
+    FS_LAUNCH_CHECK("k_jacobi_block");
+    return FS_OK;
+}
 
 template <int OP>
 static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
                         int nplanes, size_t stride, int T, float a, float den, hipStream_t stream)
 {
-    constexpr int R = 8, NW = 8;
     JacobiArgs A;
     A.g = make_gk(g);
     A.yb = yb;
@@ -164,11 +206,15 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.HX = (T + 3) & ~3;
     A.a = a;
     A.den = den;
-    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * T;
-    dim3 grid((g->width + OW - 1) / OW, (ye - yb + OH - 1) / OH, nplanes);
-    hipLaunchKernelGGL((k_jacobi_block<OP, R, NW>), grid, dim3(NW * 64), 0, stream, A);
-    FS_LAUNCH_CHECK("k_jacobi_block");
-    return FS_OK;
+    A.rden = 1.0 / (double)den;
+    switch (g_tile_variant) {
+    case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
+    case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
+    case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
+    case 4: return launch_variant<OP, 4, 16, 8>(A, g, nplanes, stream);   // 256 x 64 tile, 1024 threads
+    case 5: return launch_variant<OP, 12, 8, 3>(A, g, nplanes, stream);   // 256 x 96 tile, 512 threads
+    default: return launch_variant<OP, 8, 8, 4>(A, g, nplanes, stream);   // 256 x 64 tile, 512 threads
+    }
 }
 
 // n sweeps ping-ponging a -> b -> a ...; launch j must leave rows [yb-rem, ye+rem) valid,
@@ -184,7 +230,7 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
                   g->ye, need_lo, need_hi, g->y0, g->y0 + g->rows);
         return FS_ERR_INVALID;
     }
-    const int maxT = g_block_depth;
+    const int maxT = g_block_depth[OP];
     int rem = n;
     float *src = a, *dst = b;
     bool src_zero = a_is_zero;
@@ -205,13 +251,37 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
     return FS_OK;
 }
 
-int config_set_block_depth(int v)
+int config_set_block_depth(int op, int v)   // op < 0: both loops
 {
-    if (v < 1 || v > 24) return FS_ERR_INVALID;
-    g_block_depth = v;
+    if (v < 1 || v > 48 || op > 1) return FS_ERR_INVALID;
+    if (op < 0) g_block_depth[0] = g_block_depth[1] = v;
+    else g_block_depth[op] = v;
     return FS_OK;
 }
-int config_get_block_depth() { return g_block_depth; }
+int config_get_block_depth(int op) { return g_block_depth[op == 1 ? 1 : 0]; }
+int config_set_tile_variant(int v)
+{
+    if (v < 0 || v > 5) return FS_ERR_INVALID;
+    g_tile_variant = v;
+    return FS_OK;
+}
+int config_get_tile_variant() { return g_tile_variant; }
+
+// exhaustive check of div_const against the IEEE division: all 2^32 bit patterns of x
+__global__ __launch_bounds__(256) void k_selftest_divide(float den, double rden, unsigned long long *mismatches)
+{
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((unsigned)i);
+        const float q = x / den;
+        const float f = div_const(x, rden);
+        // NaNs compare by "both NaN"; everything else by bits (so the sign of zero is checked too)
+        const bool same = (q != q && f != f) || __float_as_uint(q) == __float_as_uint(f);
+        bad += same ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 }  // namespace fs
 
@@ -223,6 +293,19 @@ using namespace fs;
     } while (0)
 
 extern "C" {
+
+int fs_selftest_divide(float den, unsigned long long *mismatches_host)
+{
+    if (!mismatches_host || !(den > 0.0f)) return FS_ERR_INVALID;
+    unsigned long long *d = nullptr;
+    FS_HIP(hipMalloc((void **)&d, sizeof(*d)));
+    FS_HIP(hipMemset(d, 0, sizeof(*d)));
+    hipLaunchKernelGGL(k_selftest_divide, dim3(256 * 16), dim3(256), 0, nullptr, den, 1.0 / (double)den, d);
+    hipError_t e = hipMemcpy(mismatches_host, d, sizeof(*d), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fs::hip_fail(e, "fs_selftest_divide");
+    return FS_OK;
+}
 
 int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero,
                          int *result_in_b, void *stream)

@@ -226,10 +226,14 @@ __global__ __launch_bounds__(256) void k_render_velocity(GK g, int yb, int ye, c
 // write are coalesced dwords; the 4 bilinear taps per plane are a data-dependent
 // gather served by L1/L2 (neighbouring lanes trace to neighbouring cells).
 // ---------------------------------------------------------------------------
-template <int NP>
+// FADE fuses the fadeDensity pass that follows the dye advection in update() (Solver:577-591): the value
+// a cell would be given by advect is passed through max(x*(1-fade), 0) before the one store, which is
+// exactly what the separate in-place kernel computes from the stored value (Shaders:331-332).
+template <int NP, bool FADE>
 __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const float *__restrict__ u,
                                                 const float *__restrict__ v, const float *in,
-                                                float *__restrict__ out, size_t stride, float dt, int *err)
+                                                float *__restrict__ out, size_t stride, float dt, int *err,
+                                                float fade_k)
 {
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = yb + blockIdx.y * 4 + threadIdx.y;
@@ -237,7 +241,10 @@ __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const floa
     size_t o = row_off(g, y) + x;
     if (is_boundary(g, x, y)) {                               // :127-130
 #pragma unroll
-        for (int c = 0; c < NP; ++c) out[c * stride + o] = in[c * stride + o];
+        for (int c = 0; c < NP; ++c) {
+            float x = in[c * stride + o];
+            out[c * stride + o] = FADE ? fmaxf(x * fade_k, 0.0f) : x;
+        }
         return;
     }
     float posx = (float)x - u[o] * dt;                        // :132-133
@@ -260,7 +267,8 @@ __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const floa
         float q01 = p[o1], q11 = p[o1 + 1];
         float m0 = q00 + (q10 - q00) * sx;                    // :149 mix(mix(),mix(),s.y)
         float m1 = q01 + (q11 - q01) * sx;
-        out[c * stride + o] = m0 + (m1 - m0) * sy;
+        float x = m0 + (m1 - m0) * sy;
+        out[c * stride + o] = FADE ? fmaxf(x * fade_k, 0.0f) : x;
     }
 }
 
@@ -472,8 +480,8 @@ int fs_k_renderSpeed(const fs_grid *g, const float *u, const float *v, float *ou
     return FS_OK;
 }
 
-int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
-                size_t plane_stride, float deltaTime, int *err_flag, void *stream)
+static int launch_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
+                         size_t plane_stride, float deltaTime, int *err_flag, bool fade, float fadeRate, void *stream)
 {
     CHECK_GRID(g);
     REQUIRE(u && v && in && out, "null pointer");
@@ -482,13 +490,28 @@ int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *i
     EMPTY_OK(g);
     dim3 grid((g->width + 63) / 64, (g->ye - g->yb + 3) / 4, 1);
     GK gk = make_gk(g);
-    switch (nplanes) {
-    case 1: hipLaunchKernelGGL(k_advect<1>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
-    case 2: hipLaunchKernelGGL(k_advect<2>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
-    default: hipLaunchKernelGGL(k_advect<3>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag); break;
+    const float k = 1.0f - fadeRate;  // Shaders:331
+#define ADV(NP, FD) hipLaunchKernelGGL((k_advect<NP, FD>), grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag, k)
+    if (fade) {
+        switch (nplanes) { case 1: ADV(1, true); break; case 2: ADV(2, true); break; default: ADV(3, true); break; }
+    } else {
+        switch (nplanes) { case 1: ADV(1, false); break; case 2: ADV(2, false); break; default: ADV(3, false); break; }
     }
+#undef ADV
     FS_LAUNCH_CHECK("k_advect");
     return FS_OK;
+}
+
+int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
+                size_t plane_stride, float deltaTime, int *err_flag, void *stream)
+{
+    return launch_advect(g, u, v, in, out, nplanes, plane_stride, deltaTime, err_flag, false, 0.0f, stream);
+}
+
+int fs_k_advect_fade(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
+                     size_t plane_stride, float deltaTime, float fadeRate, int *err_flag, void *stream)
+{
+    return launch_advect(g, u, v, in, out, nplanes, plane_stride, deltaTime, err_flag, true, fadeRate, stream);
 }
 
 int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, float pos_x, float pos_y,

@@ -16,7 +16,8 @@ FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE, FIELD_VORTICITY
 FIELD_PLANES = {FIELD_VELOCITY: 2, FIELD_DENSITY: 3, FIELD_PRESSURE: 1, FIELD_DIVERGENCE: 1,
                 FIELD_VORTICITY: 1, FIELD_DISPLAY: 4}
 DISPLAY_NONE, DISPLAY_DENSITY, DISPLAY_VELOCITY, DISPLAY_SPEED, DISPLAY_VORTICITY, DISPLAY_PARTICLES_ONLY = -1, 0, 1, 2, 3, 4
-OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES = 0, 1, 2
+OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES, OPT_TILE_VARIANT, OPT_FUSE = 0, 1, 2, 3, 4
+OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE = 5, 6
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
  STAGE_FADE, STAGE_RENDER) = range(12)
@@ -60,6 +61,7 @@ SIGNATURES = {
     "fs_k_diffuse": (_i, [_G, _p, _p, _i, _sz, _f, _f, _p]),
     "fs_k_diffuse_n": (_i, [_G, _p, _p, _i, _sz, _f, _f, _i, C.POINTER(_i), _p]),
     "fs_k_advect": (_i, [_G, _p, _p, _p, _p, _i, _sz, _f, _p, _p]),
+    "fs_k_advect_fade": (_i, [_G, _p, _p, _p, _p, _i, _sz, _f, _f, _p, _p]),
     "fs_k_divergence": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_pressureSolve": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_pressureSolve_n": (_i, [_G, _p, _p, _p, _i, _i, C.POINTER(_i), _p]),
@@ -97,6 +99,7 @@ SIGNATURES = {
     "fs_particles_count": (_l, [_p]),
     "fs_last_error": (C.c_char_p, [_p]),
     "fs_version": (C.c_char_p, []),
+    "fs_selftest_divide": (_i, [_f, C.POINTER(C.c_ulonglong)]),
     "fs_harness_fill_uniform": (_i, [_p, _l, _f, _f, C.c_uint]),
 }
 

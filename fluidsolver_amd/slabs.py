@@ -93,6 +93,10 @@ class HipBackend:
         L.check(self.lib.fs_k_advect(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(src), self._p(dst),
                                      src.shape[0], src.stride(0), dt, C.c_void_p(err.data_ptr()), self._s()))
 
+    def advect_fade(self, g, vel, src, dst, dt, rate, err):
+        L.check(self.lib.fs_k_advect_fade(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(src), self._p(dst),
+                                          src.shape[0], src.stride(0), dt, rate, C.c_void_p(err.data_ptr()), self._s()))
+
     def fade(self, g, dye, rate):
         L.check(self.lib.fs_k_fadeDensity(C.byref(g), self._p(dye), dye.shape[0], dye.stride(0), rate, self._s()))
 
@@ -360,14 +364,23 @@ class SlabSolver:
             if ddn:
                 self._sweeps("diffuse", "dye", N, h)                           # :562-574
                 self._need("dye", h)
+            if hasattr(self.be, "advect_fade"):                                # :577-591 in one pass
+                self._advect_local("dye", fade=True)
+                if multi:
+                    V["dye"] = 0
+                return
             self._advect_local("dye")                                          # :577-584
         self.be.fade(self.grid(0), self.f["dye"], float(self.fadeSpeed))       # :587-591
         if multi:
             V["dye"] = 0
 
-    def _advect_local(self, name):
+    def _advect_local(self, name, fade=False):
         src, dst = self.f[name], self.f[name + "_t"]
-        self.be.advect(self.grid(0), self.f["vel"], src, dst, float(self.deltaTime), self.err)
+        if fade:
+            self.be.advect_fade(self.grid(0), self.f["vel"], src, dst, float(self.deltaTime), float(self.fadeSpeed),
+                                self.err)
+        else:
+            self.be.advect(self.grid(0), self.f["vel"], src, dst, float(self.deltaTime), self.err)
         self.f[name], self.f[name + "_t"] = dst, src
         if self.world > 1:
             self.valid[name] = 0

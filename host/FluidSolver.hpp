@@ -112,7 +112,9 @@ class FluidSolver {
     // addForce(at:windowSize:), :409-428; `time` replaces the wall-clock palette phase of :422-423
     void addForce(float2 at, float2 windowSize, float time)
     {
-        float2 pos = {at.x / windowSize.x * (float)scaledWidth(), at.y / windowSize.y * (float)scaledHeight()};
+        // CGPoint/CGSize are double in the reference: Float(position.x / windowSize.width) * Float(scaledWidth)
+        float2 pos = {(float)((double)at.x / (double)windowSize.x) * (float)scaledWidth(),
+                      (float)((double)at.y / (double)windowSize.y) * (float)scaledHeight()};
         float2 force = {0, 0};
         if (hasPrevious_) force = {(pos.x - previous_.x) * forceMultiplier, (pos.y - previous_.y) * forceMultiplier};
         float4 c = hsbToRgb(time, 1.0f, 1.0f);

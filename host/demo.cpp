@@ -26,7 +26,7 @@ int main(int argc, char **argv)
         double sv = 0, st = 0;
         for (float x : vel) sv += (double)x * x;
         for (float x : tex) st += (double)x;
-        std::printf("%d %d %.9e %.9e\n", n, frames, sv, st);
+        std::printf("%d %d %.17g %.17g\n", n, frames, sv, st);
     } catch (const Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
         return 1;

@@ -70,7 +70,7 @@ typedef struct fs_grid {
 int fs_pitch_for_width(int width);
 
 /* Process-wide tuning knobs of the per-kernel layer (keys: FS_OPT_BLOCK_DEPTH = sweeps fused
- * per Jacobi launch, 1..24, default 8).  No reference counterpart. */
+ * per Jacobi launch, 1..48; FS_OPT_BLOCK_DEPTH_PRESSURE / _DIFFUSE; FS_OPT_TILE_VARIANT).  No reference counterpart. */
 int fs_config_set(int key, int value);
 int fs_config_get(int key);
 
@@ -103,6 +103,13 @@ int fs_k_diffuse_n(const fs_grid *g, float *a, float *b, int nplanes, size_t pla
  * the access is clamped, never out of bounds). */
 int fs_k_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out,
                 int nplanes, size_t plane_stride, float deltaTime, int *err_flag, void *stream);
+
+/* advect followed by fadeDensity on the advected field, in one pass: replaces the two dispatches
+ * Solver:577-584 + :587-591 (kernels advect, Shaders:118-151, and fadeDensity, Shaders:326-334).
+ * Same per-cell operations in the same order, so the result equals fs_k_advect + fs_k_fadeDensity. */
+int fs_k_advect_fade(const fs_grid *g, const float *u, const float *v, const float *in, float *out,
+                     int nplanes, size_t plane_stride, float deltaTime, float fadeRate,
+                     int *err_flag, void *stream);
 
 /* replaces kernel divergence, Shaders:162-181 */
 int fs_k_divergence(const fs_grid *g, const float *u, const float *v, float *div, void *stream);
@@ -194,8 +201,13 @@ enum { FS_FIELD_VELOCITY = 0, FS_FIELD_DENSITY = 1, FS_FIELD_PRESSURE = 2,
 
 /* options for fs_set_option */
 enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph */
-       FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), default 8 */
-       FS_OPT_WITH_PARTICLES = 2  /* 1: fs_step also runs the tracer update (default 0) */ };
+       FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), both loops */
+       FS_OPT_WITH_PARTICLES = 2, /* 1: fs_step also runs the tracer update (default 0) */
+       FS_OPT_FUSE = 4,
+       FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* fs_config_set/get only: depth of the pressure loop, default 10 */
+       FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */           /* 1 (default): fs_step fuses fadeDensity into the dye advection pass */
+       FS_OPT_TILE_VARIANT = 3    /* Jacobi tile shape (rows per lane x waves): 0 = 8x8 (default), 1 = 16x8,
+                                     2 = 8x16, 3 = 16x4, 4 = 4x16, 5 = 12x8 */ };
 
 /* FluidSolver.init() + setResolution (Solver:240-255, :322-343): allocates the fields
  * of a width x height grid on HIP device `device`, all zero (clearTextures :348-366). */
@@ -247,6 +259,10 @@ long fs_particles_count(fs_ctx *ctx);
 
 const char *fs_last_error(fs_ctx *ctx); /* ctx may be NULL: last error of the calling thread */
 const char *fs_version(void);
+
+/* Self-test (GPU): counts the fp32 bit patterns x (all 2^32) for which the constant-divisor division
+ * used by the diffuse kernel differs from the IEEE division x / den.  Must return 0 mismatches. */
+int fs_selftest_divide(float den, unsigned long long *mismatches_host);
 
 /* Harness helper (host code, no GPU): xorshift32 stream -> U[lo,hi) fp32, the
  * generator SURVEY.md 8(d) names for synthetic inputs. */

@@ -215,7 +215,7 @@ def test_block_depth_does_not_change_bits(lib, oracle, depth):
     for _ in range(n):
         oracle.pressureSolve(og, div, a, b)
         a, b = b, a
-    old = lib.fs_config_get(L.OPT_BLOCK_DEPTH)
+    old = (lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE), lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE))
     try:
         ok(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
         g = grid(W, H)
@@ -225,7 +225,7 @@ def test_block_depth_does_not_change_bits(lib, oracle, depth):
         sync()
         assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
     finally:
-        lib.fs_config_set(L.OPT_BLOCK_DEPTH, old)
+        lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
 
 
 @pytest.mark.parametrize("W,H", SIZES + [(600, 150)])
@@ -374,3 +374,29 @@ def test_particles(lib, oracle):
         sync()
         for e, t in zip(exp, dev):
             assert np.array_equal(e, t.cpu().numpy())
+
+
+@pytest.mark.parametrize("den", [1.0 + 4.0 * 707.7888, 1.0000001, 3.0, 2831.1553, 1.9999999, 5.0e7, 1.0 + 4.0 * 0.0377])
+def test_constant_division_is_ieee_exact_for_all_floats(lib, den):
+    """The diffuse kernel divides by the launch-constant (1 + 4a) through an fp64 reciprocal; this checks
+    all 2^32 fp32 bit patterns against the IEEE division on the device (0 mismatches, bits compared)."""
+    bad = C.c_ulonglong(123)
+    ok(lib.fs_selftest_divide(F(den), C.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("W,H", [(177, 131), (256, 256), (33, 70)])
+def test_advect_fade_equals_advect_then_fade(lib, oracle, W, H):
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, stride, sync
+    from oracle_binding import full_grid
+    vel, den = rnd((2, H, W), 40, -6, 6), rnd((3, H, W), 41, -1, 3)
+    g, og = grid(W, H), full_grid(W, H)
+    e = np.zeros((3, H, W), F)
+    for c in range(3):
+        oracle.advect(og, vel[0], vel[1], den[c], e[c], 0.5)
+        oracle.fadeDensity(og, e[c], 0.002)
+    dv, dd, do = dev_planes(vel), dev_planes(den), dev_planes(np.zeros((3, H, W), F))
+    ok(lib.fs_k_advect_fade(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(dd), ptr(do), 3, stride(dd), 0.5, 0.002, None,
+                            stream()))
+    sync()
+    assert np.array_equal(host_planes(do, W), e)

@@ -51,7 +51,7 @@ def run_gpu_case(c, graph=True, depth=None):
 def test_golden_vectors(graph):
     from fluidsolver_amd import lib as L
     from make_golden import CASES
-    old = L.load().fs_config_get(L.OPT_BLOCK_DEPTH)
+    old = (L.load().fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE), L.load().fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE))
     try:
         for depth in (None, 3):
             for name, case in CASES.items():
@@ -60,7 +60,24 @@ def test_golden_vectors(graph):
                 for k in gold.files:
                     assert np.array_equal(out[k], gold[k]), (name, k, graph, depth)
     finally:
-        L.load().fs_config_set(L.OPT_BLOCK_DEPTH, old)
+        L.load().fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); L.load().fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
+
+
+def test_fused_and_unfused_frames_are_identical():
+    from fluidsolver_amd import lib as L
+    from make_golden import CASES
+    case = CASES["smoke_50x38"]
+    gold = np.load(os.path.join(HERE, "golden", "smoke_50x38.npz"))
+    from fluidsolver_amd.script import splat
+    for fuse in (0, 1):
+        s = make_solver(case["W"], case["H"], case["params"], case["radius"])
+        s.set_option(L.OPT_FUSE, fuse)
+        for f in range(case["frames"]):
+            pos, force, col = splat(case["W"], case["H"], f)
+            s.applyForce(pos, force, col)
+            s.update()
+        assert np.array_equal(s.read_field(L.FIELD_DENSITY), gold["den_6"]), fuse
+        assert np.array_equal(s.read_field(L.FIELD_VELOCITY), gold["vel_6"]), fuse
 
 
 def test_zero_state_stays_zero():
@@ -257,11 +274,11 @@ def test_full_size_properties():
     sync()
     ref = (pb if in_b.value else pa).clone()
     # unblocked: 40 launches of one sweep
-    old = lib.fs_config_get(L.OPT_BLOCK_DEPTH)
+    old = (lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE), lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE))
     lib.fs_config_set(L.OPT_BLOCK_DEPTH, 1)
     qa, qb = torch.zeros_like(div), torch.zeros_like(div)
     L.check(lib.fs_k_pressureSolve_n(C.byref(g), ptr(div), ptr(qa), ptr(qb), 40, 1, C.byref(in_b), stream()))
-    lib.fs_config_set(L.OPT_BLOCK_DEPTH, old)
+    lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
     sync()
     assert torch.equal(ref, qb if in_b.value else qa)
     # linearity: solve(4*div) == 4*solve(div) exactly
