@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfluidsolver_hip.so")
-SOURCES = ["passes.hip", "jacobi.hip", "context.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "fluidsolver.h")]
+SOURCES = ["passes.hip", "jacobi.hip", "context.hip", "slab.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ctx.h"), os.path.join(ROOT, "include", "fluidsolver.h")]
 
 # -ffp-contract=off: no FMA is formed, so every fp32 op rounds exactly like the CPU oracle.
 # hipcc's defaults already give correctly rounded fp32 divide/sqrt and keep denormals.
@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,13 +1,12 @@
-// context.hip -- solver context: owns the device fields of one grid and runs
-// FluidSolver.update() (Solver:477-627) as a captured hipGraph on one in-order stream.
-#include "common.h"
+// context.hip -- solver context: owns the device fields of one grid (or one row slab of it) and runs
+// FluidSolver.update() (Solver:477-627) on one in-order stream; on a single GPU as a captured hipGraph.
+#include "ctx.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
 #include <new>
-#include <unordered_map>
-#include <vector>
 
 namespace fs {
 
@@ -52,41 +51,7 @@ int check_grid(const fs_grid *g)
     return FS_OK;
 }
 
-}  // namespace fs
-
-using namespace fs;
-
-// ---------------------------------------------------------------------------
-struct fs_ctx {
-    int W = 0, H = 0, pitch = 0, device = 0;
-    size_t plane = 0;            // floats per plane
-    fs_grid grid{};
-    hipStream_t stream = nullptr;
-    // ping-pong pairs: index [cur] is the field, [cur^1] the temp (the reference swaps
-    // texture references, Solver:516,:540,:558,:572,:584)
-    float *vel[2] = {nullptr, nullptr};   // 2 planes each
-    float *den[2] = {nullptr, nullptr};   // 3 planes each
-    float *prs[2] = {nullptr, nullptr};
-    float *div = nullptr, *vort = nullptr;
-    float *display = nullptr;             // 4 planes
-    int vcur = 0, dcur = 0, pcur = 0;
-    int *err_flag = nullptr;              // device
-    fs_params params{};
-    unsigned params_version = 0;
-    int use_graph = 1;
-    int with_particles = 0;
-    int fuse = 1;
-    std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
-    std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
-    // tracers
-    long max_particles = 0, n_particles = 0;
-    float *part[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    fs_particle_params pparams{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
-    char error[512] = "";
-};
-
-static int ctx_fail(fs_ctx *c, int rc)
+int ctx_fail(fs_ctx *c, int rc)
 {
     if (c) {
         strncpy(c->error, fs::get_error(), sizeof(c->error) - 1);
@@ -94,22 +59,10 @@ static int ctx_fail(fs_ctx *c, int rc)
     }
     return rc;
 }
-#define CTX(c)                                             \
-    do {                                                   \
-        if (!(c)) { fs::set_error("ctx is NULL"); return FS_ERR_INVALID; } \
-        hipError_t e_ = hipSetDevice((c)->device);         \
-        if (e_ != hipSuccess) return ctx_fail(c, fs::hip_fail(e_, "hipSetDevice")); \
-    } while (0)
-#define TRY(c, call)                        \
-    do {                                    \
-        int rc_ = (call);                   \
-        if (rc_) return ctx_fail(c, rc_);   \
-    } while (0)
-#define TRYHIP(c, call)                                            \
-    do {                                                           \
-        hipError_t e_ = (call);                                    \
-        if (e_ != hipSuccess) return ctx_fail(c, fs::hip_fail(e_, #call)); \
-    } while (0)
+
+}  // namespace fs
+
+using namespace fs;
 
 static void drop_graphs(fs_ctx *c)
 {
@@ -130,151 +83,135 @@ static int nplanes_of(int field)
     }
     return 0;
 }
-static float *field_ptr(fs_ctx *c, int field)
+static int field_index(int field)
 {
     switch (field) {
-    case FS_FIELD_VELOCITY: return c->vel[c->vcur];
-    case FS_FIELD_DENSITY: return c->den[c->dcur];
-    case FS_FIELD_PRESSURE: return c->prs[c->pcur];
-    case FS_FIELD_DIVERGENCE: return c->div;
-    case FS_FIELD_VORTICITY: return c->vort;
-    case FS_FIELD_DISPLAY: return c->display;
+    case FS_FIELD_VELOCITY: return F_VEL;
+    case FS_FIELD_DENSITY: return F_DYE;
+    case FS_FIELD_PRESSURE: return F_P;
+    case FS_FIELD_DIVERGENCE: return F_DIV;
+    case FS_FIELD_VORTICITY: return F_VORT;
     }
-    return nullptr;
+    return -1;
+}
+static float *field_ptr(fs_ctx *c, int field)
+{
+    if (field == FS_FIELD_DISPLAY) return c->display;
+    const int i = field_index(field);
+    return i < 0 ? nullptr : c->f[i].p();
 }
 
-// ---- the stages of update(), on the context's own buffers -------------------
-static int st_vorticity(fs_ctx *c)
+#define SINGLE(c, what)                                                                              \
+    do {                                                                                             \
+        if ((c)->world > 1) { fs::set_error(what " is not available on a slab of a multi-GPU run"); \
+                              return fs::ctx_fail(c, FS_ERR_STATE); }                                \
+    } while (0)
+
+// ---- the stages of update(), on the context's own buffers (single GPU) ----------------------
+static int st_sweeps(fs_ctx *c, int fi, int n, bool pressure, bool p_is_zero)
 {
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    return fs_k_calculateVorticity(&c->grid, u, v, c->vort, c->stream);               // Solver:488-491
-}
-static int st_apply_vorticity(fs_ctx *c)
-{
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    return fs_k_applyVorticity(&c->grid, c->vort, u, v, c->params.vorticityStrength,  // Solver:494-501
-                               c->params.deltaTime, c->stream);
-}
-static int st_diffuse_velocity(fs_ctx *c, int n)
-{
-    int in_b = 0;
-    int rc = fs_k_diffuse_n(&c->grid, c->vel[c->vcur], c->vel[c->vcur ^ 1], 2, c->plane,  // Solver:506-517
-                            c->params.viscosity, c->params.deltaTime, n, &in_b, c->stream);
-    if (!rc && in_b) c->vcur ^= 1;
+    Field &F = c->f[fi];
+    int in_b = 0, rc;
+    if (pressure)
+        rc = fs_k_pressureSolve_n(&c->grid, c->f[F_DIV].p(), F.p(), F.t(), n, p_is_zero ? 1 : 0, &in_b, c->stream);  // Solver:533-541
+    else
+        rc = fs_k_diffuse_n(&c->grid, F.p(), F.t(), F.np, c->plane, fi == F_VEL ? c->params.viscosity : c->params.diffusion,
+                            c->params.deltaTime, n, &in_b, c->stream);                 // Solver:506-517, :563-573
+    if (!rc && in_b) F.cur ^= 1;
     return rc;
 }
-static int st_divergence(fs_ctx *c)
+static int st_advect(fs_ctx *c, int fi)
 {
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    return fs_k_divergence(&c->grid, u, v, c->div, c->stream);                        // Solver:522-525
-}
-static int st_clear_pressure(fs_ctx *c)
-{
-    return fs_k_clear(&c->grid, c->prs[c->pcur], 1, 0, c->stream);                    // Solver:528-530
-}
-static int st_pressure(fs_ctx *c, int n, bool p_is_zero)
-{
-    int in_b = 0;
-    int rc = fs_k_pressureSolve_n(&c->grid, c->div, c->prs[c->pcur], c->prs[c->pcur ^ 1], n, p_is_zero ? 1 : 0,
-                                  &in_b, c->stream);                                  // Solver:533-541
-    if (!rc && in_b) c->pcur ^= 1;
+    Field &F = c->f[fi];
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
+    int rc = fs_k_advect(&c->grid, u, v, F.p(), F.t(), F.np, c->plane, c->params.deltaTime, c->err_flag, c->stream);   // Solver:550-556, :577-582
+    if (!rc) F.cur ^= 1;                                                               // :558, :584
     return rc;
-}
-static int st_subtract_gradient(fs_ctx *c)
-{
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    return fs_k_subtractGradient(&c->grid, c->prs[c->pcur], u, v, c->stream);         // Solver:544-547
-}
-static int st_advect_velocity(fs_ctx *c)
-{
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    int rc = fs_k_advect(&c->grid, u, v, u, c->vel[c->vcur ^ 1], 2, c->plane, c->params.deltaTime, c->err_flag,
-                         c->stream);                                                  // Solver:550-556
-    if (!rc) c->vcur ^= 1;                                                            // :558
-    return rc;
-}
-static int st_diffuse_density(fs_ctx *c, int n)
-{
-    int in_b = 0;
-    int rc = fs_k_diffuse_n(&c->grid, c->den[c->dcur], c->den[c->dcur ^ 1], 3, c->plane,  // Solver:563-573
-                            c->params.diffusion, c->params.deltaTime, n, &in_b, c->stream);
-    if (!rc && in_b) c->dcur ^= 1;
-    return rc;
-}
-static int st_advect_density(fs_ctx *c)
-{
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    int rc = fs_k_advect(&c->grid, u, v, c->den[c->dcur], c->den[c->dcur ^ 1], 3, c->plane, c->params.deltaTime,
-                         c->err_flag, c->stream);                                     // Solver:577-582
-    if (!rc) c->dcur ^= 1;                                                            // :584
-    return rc;
-}
-static int st_advect_density_fade(fs_ctx *c)
-{
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    int rc = fs_k_advect_fade(&c->grid, u, v, c->den[c->dcur], c->den[c->dcur ^ 1], 3, c->plane,
-                              c->params.deltaTime, c->params.fadeSpeed, c->err_flag, c->stream);  // Solver:577-591
-    if (!rc) c->dcur ^= 1;
-    return rc;
-}
-static int st_fade(fs_ctx *c)
-{
-    return fs_k_fadeDensity(&c->grid, c->den[c->dcur], 3, c->plane, c->params.fadeSpeed, c->stream);  // Solver:587-591
 }
 static int st_render(fs_ctx *c)
 {
-    float *u = c->vel[c->vcur], *v = u + c->plane;
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
     switch (c->params.displayMode) {                                                  // Solver:594-623
     case FS_DISPLAY_DENSITY:
-        return fs_k_renderDensity(&c->grid, c->den[c->dcur], c->plane, 3, c->display, c->plane, c->params.brightness,
-                                  c->stream);
+        return fs_k_renderDensity(&c->grid, c->f[F_DYE].p(), c->plane, 3, c->display, c->plane, c->params.brightness, c->stream);
     case FS_DISPLAY_VELOCITY: return fs_k_renderVelocity(&c->grid, u, v, c->display, c->plane, 1.0f, c->stream);
     case FS_DISPLAY_SPEED: return fs_k_renderSpeed(&c->grid, u, v, c->display, c->plane, 25.0f, c->stream);
     case FS_DISPLAY_VORTICITY:
-        return fs_k_renderDensity(&c->grid, c->vort, c->plane, 1, c->display, c->plane, 10.0f, c->stream);
+        return fs_k_renderDensity(&c->grid, c->f[F_VORT].p(), c->plane, 1, c->display, c->plane, 10.0f, c->stream);
     case FS_DISPLAY_PARTICLES_ONLY: return fs_k_clear(&c->grid, c->display, 4, c->plane, c->stream);
     default: return FS_OK;  // FS_DISPLAY_NONE: headless
     }
 }
 static int st_particles(fs_ctx *c)
 {
-    float *u = c->vel[c->vcur], *v = u + c->plane;
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
     return fs_k_particles_update(&c->grid, u, v, &c->pparams, c->n_particles, c->part[0], c->part[1], c->part[2],
                                  c->part[3], c->part[4], c->part[5], c->part[6], c->stream);
 }
 
-// the whole of update(): Solver:477-627
-static int enqueue_update(fs_ctx *c)
+// Allocates one slab (world 1: the whole grid).  dry = plan-only context without device memory.
+int create_common(int width, int height, int device, fs_comm *comm, int world, int rank, int ghost_rows,
+                  long max_particles, bool dry, fs_ctx **out)
 {
-    const fs_params &p = c->params;
-    const int N = p.solverIterations;
-    int rc;
-    if (p.vorticityStrength > 0.0f) {                            // :486
-        if ((rc = st_vorticity(c))) return rc;
-        if ((rc = st_apply_vorticity(c))) return rc;
+    if (!out) { fs::set_error("fs_create: out is NULL"); return FS_ERR_INVALID; }
+    *out = nullptr;
+    if (width < 1 || height < 1 || width > (1 << 22) || height > (1 << 22) || max_particles < 0) {
+        fs::set_error("fs_create: bad size %dx%d / %ld particles", width, height, max_particles);
+        return FS_ERR_INVALID;
     }
-    if (p.viscosity > 0.0f) {                                    // :505
-        if ((rc = st_diffuse_velocity(c, N))) return rc;
+    const int own_min = height / world;
+    if (world > 1 && own_min < 4) { fs::set_error("slabs of %d rows are too thin for %d ranks", own_min, world); return FS_ERR_INVALID; }
+    int G = 0;
+    if (world > 1) {
+        G = ghost_rows < 0 ? own_min : std::min(ghost_rows, height);   // > own_min: multi-hop exchange
+        if (G < 2) { fs::set_error("ghost capacity must be >= 2 rows"); return FS_ERR_INVALID; }
     }
-    if ((rc = st_divergence(c))) return rc;                      // :522
-    // clear (:528-530) is folded into the first pressure sweep (p_is_zero); with N == 0
-    // fs_k_pressureSolve_n clears explicitly.
-    if ((rc = st_pressure(c, N, true))) return rc;               // :533-541
-    if ((rc = st_subtract_gradient(c))) return rc;               // :544
-    if ((rc = st_advect_velocity(c))) return rc;                 // :550-558
-    if (p.diffusion > 0.0f) {                                    // :562
-        if ((rc = st_diffuse_density(c, N))) return rc;
+    if (!dry) FS_HIP(hipSetDevice(device));
+    fs_ctx *c = new (std::nothrow) fs_ctx();
+    if (!c) return FS_ERR_NOMEM;
+    c->W = width; c->H = height; c->device = device;
+    c->comm = comm; c->world = world; c->rank = rank; c->G = G; c->dry = dry;
+    fs::slab_rows(height, world, rank, &c->r0, &c->r1);
+    c->b0 = std::max(0, c->r0 - G);
+    c->b1 = std::min(height, c->r1 + G);
+    c->pitch = fs_pitch_for_width(width);
+    c->plane = (size_t)c->pitch * (size_t)(c->b1 - c->b0);
+    c->grid = fs::grid_of(c, 0);
+    c->f[F_VEL].np = 2; c->f[F_DYE].np = 3;
+    fs_default_params(&c->params);
+    fs_default_particle_params(&c->pparams, (float)width, (float)height);
+    c->max_particles = max_particles;
+    if (dry) { *out = c; return FS_OK; }
+    int rc = FS_OK;
+    auto alloc = [&](float **p, size_t nplanes) {
+        if (rc) return;
+        hipError_t e = hipMalloc((void **)p, nplanes * c->plane * sizeof(float));
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(field)");
+    };
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = fs::hip_fail(e, "hipStreamCreate");
+    for (int i = 0; i < 2; ++i) { alloc(&c->f[F_VEL].buf[i], 2); alloc(&c->f[F_DYE].buf[i], 3); alloc(&c->f[F_P].buf[i], 1); }
+    alloc(&c->f[F_DIV].buf[0], 1); alloc(&c->f[F_VORT].buf[0], 1); alloc(&c->display, 4);
+    if (!rc) {
+        e = hipMalloc((void **)&c->err_flag, sizeof(int));
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(err_flag)");
     }
-    if (c->fuse) {
-        if ((rc = st_advect_density_fade(c))) return rc;         // :577-591 in one pass
-    } else {
-        if ((rc = st_advect_density(c))) return rc;              // :577-584
-        if ((rc = st_fade(c))) return rc;                        // :587
+    if (!rc) {
+        e = hipMalloc((void **)&c->cfl_dev, sizeof(float));
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(cfl)");
     }
-    if ((rc = st_render(c))) return rc;                          // :594-623
-    if (c->with_particles && c->n_particles > 0) {
-        if ((rc = st_particles(c))) return rc;                   // MetalView.swift:155 -> Part:242
+    if (!rc) {
+        e = hipHostMalloc((void **)&c->cfl_host, sizeof(float), hipHostMallocDefault);
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipHostMalloc(cfl)");
     }
+    for (int i = 0; i < 7 && !rc && max_particles > 0; ++i) {
+        e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(particles)");
+    }
+    if (rc) { fs_destroy(c); return rc; }
+    rc = fs_reset(c);
+    if (rc) { fs_destroy(c); return rc; }
+    *out = c;
     return FS_OK;
 }
 
@@ -282,7 +219,7 @@ extern "C" {
 
 int fs_pitch_for_width(int width) { return width < 1 ? 0 : (width + 63) & ~63; }
 
-const char *fs_version(void) { return "fluidsolver_amd 0.1 (gfx950)"; }
+const char *fs_version(void) { return "fluidsolver_amd 0.2 (gfx950)"; }
 
 const char *fs_last_error(fs_ctx *ctx) { return ctx ? ctx->error : fs::get_error(); }
 
@@ -315,55 +252,21 @@ int fs_default_particle_params(fs_particle_params *pp, float windowW, float wind
 
 int fs_create(int width, int height, int device, long max_particles, fs_ctx **out)
 {
-    if (!out) { fs::set_error("fs_create: out is NULL"); return FS_ERR_INVALID; }
-    *out = nullptr;
-    if (width < 1 || height < 1 || width > (1 << 22) || height > (1 << 22) || max_particles < 0) {
-        fs::set_error("fs_create: bad size %dx%d / %ld particles", width, height, max_particles);
-        return FS_ERR_INVALID;
-    }
-    FS_HIP(hipSetDevice(device));
-    fs_ctx *c = new (std::nothrow) fs_ctx();
-    if (!c) return FS_ERR_NOMEM;
-    c->W = width; c->H = height; c->device = device;
-    c->pitch = fs_pitch_for_width(width);
-    c->plane = (size_t)c->pitch * (size_t)height;
-    c->grid = fs_grid{width, height, c->pitch, 0, height, 0, height};
-    fs_default_params(&c->params);
-    fs_default_particle_params(&c->pparams, (float)width, (float)height);
-    c->max_particles = max_particles;
-    int rc = FS_OK;
-    auto alloc = [&](float **p, size_t nplanes) {
-        if (rc) return;
-        hipError_t e = hipMalloc((void **)p, nplanes * c->plane * sizeof(float));
-        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(field)");
-    };
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) rc = fs::hip_fail(e, "hipStreamCreate");
-    for (int i = 0; i < 2; ++i) { alloc(&c->vel[i], 2); alloc(&c->den[i], 3); alloc(&c->prs[i], 1); }
-    alloc(&c->div, 1); alloc(&c->vort, 1); alloc(&c->display, 4);
-    if (!rc) {
-        e = hipMalloc((void **)&c->err_flag, sizeof(int));
-        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(err_flag)");
-    }
-    for (int i = 0; i < 7 && !rc && max_particles > 0; ++i) {
-        e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
-        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(particles)");
-    }
-    if (rc) { fs_destroy(c); return rc; }
-    rc = fs_reset(c);
-    if (rc) { fs_destroy(c); return rc; }
-    *out = c;
-    return FS_OK;
+    return create_common(width, height, device, nullptr, 1, 0, 0, max_particles, false, out);
 }
 
 int fs_destroy(fs_ctx *c)
 {
     if (!c) return FS_OK;
+    if (c->dry) { delete c; return FS_OK; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graphs(c);
-    for (int i = 0; i < 2; ++i) { (void)hipFree(c->vel[i]); (void)hipFree(c->den[i]); (void)hipFree(c->prs[i]); }
-    (void)hipFree(c->div); (void)hipFree(c->vort); (void)hipFree(c->display); (void)hipFree(c->err_flag);
+    if (c->comm && c->comm->kind == 0 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
+        c->comm->members[c->rank] = nullptr;
+    for (int i = 0; i < F_COUNT; ++i) { (void)hipFree(c->f[i].buf[0]); (void)hipFree(c->f[i].buf[1]); }
+    (void)hipFree(c->display); (void)hipFree(c->err_flag); (void)hipFree(c->cfl_dev);
+    if (c->cfl_host) (void)hipHostFree(c->cfl_host);
     for (int i = 0; i < 7; ++i) (void)hipFree(c->part[i]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -378,13 +281,11 @@ int fs_reset(fs_ctx *c)
 {
     CTX(c);
     const size_t pb = c->plane * sizeof(float);
-    for (int i = 0; i < 2; ++i) {
-        TRYHIP(c, hipMemsetAsync(c->vel[i], 0, 2 * pb, c->stream));
-        TRYHIP(c, hipMemsetAsync(c->den[i], 0, 3 * pb, c->stream));
-        TRYHIP(c, hipMemsetAsync(c->prs[i], 0, pb, c->stream));
+    for (int i = 0; i < F_COUNT; ++i) {
+        for (int k = 0; k < 2; ++k)
+            if (c->f[i].buf[k]) TRYHIP(c, hipMemsetAsync(c->f[i].buf[k], 0, c->f[i].np * pb, c->stream));
+        c->f[i].valid = kInf;   // an all-zero field is valid at any ghost depth
     }
-    TRYHIP(c, hipMemsetAsync(c->div, 0, pb, c->stream));
-    TRYHIP(c, hipMemsetAsync(c->vort, 0, pb, c->stream));
     TRYHIP(c, hipMemsetAsync(c->display, 0, 4 * pb, c->stream));
     TRYHIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
     return FS_OK;
@@ -424,7 +325,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
     case FS_OPT_FUSE: c->fuse = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:
-        if (fs::config_set_tile_variant(value)) { fs::set_error("tile variant %d out of range 0..5", value); return ctx_fail(c, FS_ERR_INVALID); }
+        if (fs::config_set_tile_variant(value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
@@ -432,40 +333,59 @@ int fs_set_option(fs_ctx *c, int option, int value)
     return FS_OK;
 }
 
+// applyForce, Solver:444-470.  A slab applies the splat to every row it holds (owned + ghost), so
+// ghost depths survive a splat.
 int fs_add_force(fs_ctx *c, float pos_x, float pos_y, float force_x, float force_y, const float color_rgba[4],
                  float radius, float deltaTime)
 {
     CTX(c);
     if (!color_rgba) { fs::set_error("color is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
-    float *u = c->vel[c->vcur], *v = u + c->plane;
-    float *d = c->den[c->dcur];
-    TRY(c, fs_k_addForces(&c->grid, u, v, d, d + c->plane, d + 2 * c->plane, pos_x, pos_y, force_x, force_y,
+    const fs_grid g = fs::grid_of(c, c->G);
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
+    float *d = c->f[F_DYE].p();
+    TRY(c, fs_k_addForces(&g, u, v, d, d + c->plane, d + 2 * c->plane, pos_x, pos_y, force_x, force_y,
                           color_rgba[0], color_rgba[1], color_rgba[2], radius, deltaTime, c->stream));
     return FS_OK;
+}
+
+static unsigned long long pingpong_key(const fs_ctx *c)
+{
+    return (unsigned long long)c->f[F_VEL].cur | ((unsigned long long)c->f[F_DYE].cur << 1) |
+           ((unsigned long long)c->f[F_P].cur << 2);
+}
+static void set_pingpong(fs_ctx *c, unsigned long long k)
+{
+    c->f[F_VEL].cur = (int)(k & 1); c->f[F_DYE].cur = (int)((k >> 1) & 1); c->f[F_P].cur = (int)((k >> 2) & 1);
 }
 
 int fs_step(fs_ctx *c)
 {
     CTX(c);
+    if (c->world > 1) {
+        if (!c->comm || c->comm->kind != 1) {
+            fs::set_error("fs_step: a slab of an in-process group is stepped by fs_group_step");
+            return ctx_fail(c, FS_ERR_STATE);
+        }
+        TRY(c, fs::run_frame(c));
+        return FS_OK;
+    }
     if (!c->use_graph) {
-        TRY(c, enqueue_update(c));
+        TRY(c, fs::run_frame(c));
         return FS_OK;
     }
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph
     // is keyed by the ping-pong state it was recorded from.
-    const unsigned long long key = (unsigned long long)c->vcur | ((unsigned long long)c->dcur << 1) |
-                                   ((unsigned long long)c->pcur << 2) |
-                                   ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3);
+    const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
-        const int v0 = c->vcur, d0 = c->dcur, p0 = c->pcur;
+        const unsigned long long before = pingpong_key(c);
         hipGraph_t graph = nullptr;
         TRYHIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_update(c);
+        int rc = fs::run_frame(c);
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc || e != hipSuccess) {
             if (graph) (void)hipGraphDestroy(graph);
-            c->vcur = v0; c->dcur = d0; c->pcur = p0;
+            set_pingpong(c, before);
             if (rc) return ctx_fail(c, rc);
             return ctx_fail(c, fs::hip_fail(e, "hipStreamEndCapture"));
         }
@@ -473,20 +393,18 @@ int fs_step(fs_ctx *c)
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
-            c->vcur = v0; c->dcur = d0; c->pcur = p0;
+            set_pingpong(c, before);
             return ctx_fail(c, fs::hip_fail(e, "hipGraphInstantiate"));
         }
         // remember where the roles end up so replays can update them without re-recording
-        const unsigned long long after = (unsigned long long)c->vcur | ((unsigned long long)c->dcur << 1) |
-                                         ((unsigned long long)c->pcur << 2);
         c->graphs[key] = exec;
-        c->graphs_after[key] = after;
+        c->graphs_after[key] = pingpong_key(c);
         TRYHIP(c, hipGraphLaunch(exec, c->stream));
         return FS_OK;
     }
     TRYHIP(c, hipGraphLaunch(it->second, c->stream));
-    const unsigned long long after = c->graphs_after[key];
-    c->vcur = (int)(after & 1); c->dcur = (int)((after >> 1) & 1); c->pcur = (int)((after >> 2) & 1);
+    set_pingpong(c, c->graphs_after[key]);
+    c->stat_frames += 1;
     return FS_OK;
 }
 
@@ -504,36 +422,40 @@ int fs_sync(fs_ctx *c)
     return FS_OK;
 }
 
+// Host copies move the rows this context OWNS: dense planar [plane][r1-r0][width] (the whole field on one GPU).
+static int copy_field(fs_ctx *c, int field, float *host, size_t bytes, bool to_host, const char *who)
+{
+    const int np = nplanes_of(field);
+    if (!np || !host) { fs::set_error("%s: bad field %d or NULL host pointer", who, field); return ctx_fail(c, FS_ERR_INVALID); }
+    const size_t rows = (size_t)(c->r1 - c->r0);
+    const size_t need = (size_t)np * c->W * rows * sizeof(float);
+    if (bytes != need) { fs::set_error("%s: expected %zu bytes, got %zu", who, need, bytes); return ctx_fail(c, FS_ERR_INVALID); }
+    TRYHIP(c, hipStreamSynchronize(c->stream));
+    float *dev = field_ptr(c, field) + (size_t)(c->r0 - c->b0) * c->pitch;
+    const size_t hp = (size_t)c->W * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
+    for (int p = 0; p < np; ++p) {
+        float *h = host + (size_t)p * c->W * rows;
+        float *d = dev + p * c->plane;
+        if (to_host) TRYHIP(c, hipMemcpy2D(h, hp, d, dp, hp, rows, hipMemcpyDeviceToHost));
+        else TRYHIP(c, hipMemcpy2D(d, dp, h, hp, hp, rows, hipMemcpyHostToDevice));
+    }
+    if (!to_host && c->world > 1) {
+        const int i = field_index(field);
+        if (i >= 0) c->f[i].valid = 0;   // the ghost rows no longer mirror the neighbours
+    }
+    return FS_OK;
+}
+
 int fs_read_field(fs_ctx *c, int field, float *host, size_t bytes)
 {
     CTX(c);
-    const int np = nplanes_of(field);
-    if (!np || !host) { fs::set_error("fs_read_field: bad field %d or NULL host pointer", field); return ctx_fail(c, FS_ERR_INVALID); }
-    const size_t need = (size_t)np * c->W * c->H * sizeof(float);
-    if (bytes != need) { fs::set_error("fs_read_field: expected %zu bytes, got %zu", need, bytes); return ctx_fail(c, FS_ERR_INVALID); }
-    TRYHIP(c, hipStreamSynchronize(c->stream));
-    const float *src = field_ptr(c, field);
-    for (int p = 0; p < np; ++p)
-        TRYHIP(c, hipMemcpy2D(host + (size_t)p * c->W * c->H, (size_t)c->W * sizeof(float), src + p * c->plane,
-                              (size_t)c->pitch * sizeof(float), (size_t)c->W * sizeof(float), c->H,
-                              hipMemcpyDeviceToHost));
-    return FS_OK;
+    return copy_field(c, field, host, bytes, true, "fs_read_field");
 }
 
 int fs_write_field(fs_ctx *c, int field, const float *host, size_t bytes)
 {
     CTX(c);
-    const int np = nplanes_of(field);
-    if (!np || !host) { fs::set_error("fs_write_field: bad field %d or NULL host pointer", field); return ctx_fail(c, FS_ERR_INVALID); }
-    const size_t need = (size_t)np * c->W * c->H * sizeof(float);
-    if (bytes != need) { fs::set_error("fs_write_field: expected %zu bytes, got %zu", need, bytes); return ctx_fail(c, FS_ERR_INVALID); }
-    TRYHIP(c, hipStreamSynchronize(c->stream));
-    float *dst = field_ptr(c, field);
-    for (int p = 0; p < np; ++p)
-        TRYHIP(c, hipMemcpy2D(dst + p * c->plane, (size_t)c->pitch * sizeof(float), host + (size_t)p * c->W * c->H,
-                              (size_t)c->W * sizeof(float), (size_t)c->W * sizeof(float), c->H,
-                              hipMemcpyHostToDevice));
-    return FS_OK;
+    return copy_field(c, field, const_cast<float *>(host), bytes, false, "fs_write_field");
 }
 
 int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pitch)
@@ -569,20 +491,24 @@ int fs_timer_end(fs_ctx *c, float *ms)
 int fs_stage(fs_ctx *c, int stage, int n)
 {
     CTX(c);
+    SINGLE(c, "fs_stage");
     if (n < 0) { fs::set_error("negative sweep count"); return ctx_fail(c, FS_ERR_INVALID); }
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
     int rc;
     switch (stage) {
-    case FS_STAGE_VORTICITY: rc = st_vorticity(c); break;
-    case FS_STAGE_APPLY_VORTICITY: rc = st_apply_vorticity(c); break;
-    case FS_STAGE_DIFFUSE_VELOCITY: rc = st_diffuse_velocity(c, n); break;
-    case FS_STAGE_DIVERGENCE: rc = st_divergence(c); break;
-    case FS_STAGE_CLEAR_PRESSURE: rc = st_clear_pressure(c); break;
-    case FS_STAGE_PRESSURE: rc = st_pressure(c, n, false); break;
-    case FS_STAGE_SUBTRACT_GRADIENT: rc = st_subtract_gradient(c); break;
-    case FS_STAGE_ADVECT_VELOCITY: rc = st_advect_velocity(c); break;
-    case FS_STAGE_DIFFUSE_DENSITY: rc = st_diffuse_density(c, n); break;
-    case FS_STAGE_ADVECT_DENSITY: rc = st_advect_density(c); break;
-    case FS_STAGE_FADE: rc = st_fade(c); break;
+    case FS_STAGE_VORTICITY: rc = fs_k_calculateVorticity(&c->grid, u, v, c->f[F_VORT].p(), c->stream); break;      // Solver:488-491
+    case FS_STAGE_APPLY_VORTICITY:
+        rc = fs_k_applyVorticity(&c->grid, c->f[F_VORT].p(), u, v, c->params.vorticityStrength, c->params.deltaTime, c->stream);   // :494-501
+        break;
+    case FS_STAGE_DIFFUSE_VELOCITY: rc = st_sweeps(c, F_VEL, n, false, false); break;
+    case FS_STAGE_DIVERGENCE: rc = fs_k_divergence(&c->grid, u, v, c->f[F_DIV].p(), c->stream); break;              // :522-525
+    case FS_STAGE_CLEAR_PRESSURE: rc = fs_k_clear(&c->grid, c->f[F_P].p(), 1, 0, c->stream); break;                 // :528-530
+    case FS_STAGE_PRESSURE: rc = st_sweeps(c, F_P, n, true, false); break;
+    case FS_STAGE_SUBTRACT_GRADIENT: rc = fs_k_subtractGradient(&c->grid, c->f[F_P].p(), u, v, c->stream); break;   // :544-547
+    case FS_STAGE_ADVECT_VELOCITY: rc = st_advect(c, F_VEL); break;
+    case FS_STAGE_DIFFUSE_DENSITY: rc = st_sweeps(c, F_DYE, n, false, false); break;
+    case FS_STAGE_ADVECT_DENSITY: rc = st_advect(c, F_DYE); break;
+    case FS_STAGE_FADE: rc = fs_k_fadeDensity(&c->grid, c->f[F_DYE].p(), 3, c->plane, c->params.fadeSpeed, c->stream); break;   // :587-591
     case FS_STAGE_RENDER: rc = st_render(c); break;
     default: fs::set_error("unknown stage %d", stage); rc = FS_ERR_INVALID;
     }
@@ -593,6 +519,7 @@ int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const 
                      const float *life, const float *mass, const float *age)
 {
     CTX(c);
+    SINGLE(c, "tracers");
     if (n < 0 || n > c->max_particles) { fs::set_error("particle count %ld exceeds capacity %ld", n, c->max_particles); return ctx_fail(c, FS_ERR_INVALID); }
     const float *src[7] = {px, py, vx, vy, life, mass, age};
     TRYHIP(c, hipStreamSynchronize(c->stream));
@@ -622,6 +549,7 @@ long fs_particles_count(fs_ctx *c) { return c ? c->n_particles : 0; }
 int fs_particles_update(fs_ctx *c, const fs_particle_params *pp)
 {
     CTX(c);
+    SINGLE(c, "tracers");
     if (pp) {
         if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
     }

@@ -1,0 +1,128 @@
+// ctx.h -- private layout of the solver context (shared by context.hip and slab.hip).
+//
+// One context = one ROW SLAB of a W x H solver: global rows [r0, r1) owned, plus up to G ghost
+// rows on each interior side held in the same buffers (rows [b0, b1)).  A single GPU is the
+// one-slab case: r0 = b0 = 0, r1 = b1 = H, G = 0, no communicator.
+#pragma once
+#include "common.h"
+#include <functional>
+#include <unordered_map>
+#include <vector>
+
+namespace fs {
+
+enum { F_VEL = 0, F_DYE, F_P, F_DIV, F_VORT, F_COUNT };
+constexpr int kInf = 1 << 30;
+
+// A field and its ping-pong partner (the reference swaps texture references, Solver:516,:540,:558,
+// :572,:584).  `valid` = how many ghost rows beside the owned rows still equal the neighbour's
+// owned rows (kInf: everywhere, e.g. an all-zero field).
+struct Field {
+    float *buf[2] = {nullptr, nullptr};
+    int cur = 0;
+    int np = 1;
+    int valid = kInf;
+    float *p() const { return buf[cur]; }
+    float *t() const { return buf[cur ^ 1]; }
+};
+
+struct Xfer {
+    int field, bufidx, depth;   // refresh the ghost rows of f[field].buf[bufidx] to `depth` rows
+};
+
+enum { STEP_COMPUTE = 0, STEP_EXCHANGE = 1, STEP_CFL_REDUCE = 2 };
+
+// One entry of a frame plan.  The plan of a frame is the same on every rank (same kinds, same
+// depths), which is what lets an in-process group run K slabs in lock step.
+struct Step {
+    int kind = STEP_COMPUTE;
+    const char *what = "";
+    int yb = 0, ye = 0, n = 0;          // rows computed / sweeps (plan dumps, tests)
+    std::function<int()> run;           // STEP_COMPUTE: enqueue the kernel(s) on the context's stream
+    std::vector<Xfer> xf;               // STEP_EXCHANGE
+};
+
+void slab_rows(int H, int world, int rank, int *r0, int *r1);
+
+}  // namespace fs
+
+// Transport of the halo exchange.  kind 1 = RCCL (one process per GPU, ncclSend/ncclRecv over xGMI);
+// kind 0 = in-process group (all slabs live in this process; copies are plain device memcpys) used
+// to test the slab logic on a 1-GPU box.
+struct fs_comm {
+    int kind = 0;
+    int world = 1;
+    int rank = 0;                       // RCCL only
+    int device = 0;                     // RCCL only
+    void *nccl = nullptr;               // ncclComm_t
+    std::vector<fs_ctx *> members;      // local group: index = rank
+};
+
+struct fs_ctx {
+    int W = 0, H = 0, pitch = 0, device = 0;
+    // slab geometry
+    fs_comm *comm = nullptr;
+    int world = 1, rank = 0;
+    int r0 = 0, r1 = 0;                 // owned rows
+    int b0 = 0, b1 = 0;                 // rows held by the buffers
+    int G = 0;                          // ghost capacity per side
+    bool dry = false;                   // plan-only context (no device memory), fs_slab_plan_dump
+    size_t plane = 0;                   // floats per plane = pitch * (b1 - b0)
+    fs_grid grid{};                     // owned rows (the whole grid on one GPU)
+    hipStream_t stream = nullptr;
+    fs::Field f[fs::F_COUNT];
+    float *display = nullptr;           // 4 planes
+    int *err_flag = nullptr;            // device
+    float *cfl_dev = nullptr;           // device: max |v_y| of the owned rows
+    float *cfl_host = nullptr;          // pinned
+    float cfl_max = 0.0f;               // all-reduced value of the current frame
+    fs_params params{};
+    int use_graph = 1;
+    int with_particles = 0;
+    int fuse = 1;
+    bool p_zero = false;                // planner state: pressure iterate is implicitly 0
+    std::vector<fs::Step> steps;
+    std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
+    std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
+    // statistics of the slab path
+    long stat_exchanges = 0, stat_rows = 0, stat_frames = 0;
+    int last_halo = 0;
+    // tracers
+    long max_particles = 0, n_particles = 0;
+    float *part[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fs_particle_params pparams{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
+    char error[512] = "";
+};
+
+namespace fs {
+
+int ctx_fail(fs_ctx *c, int rc);
+fs_grid grid_of(const fs_ctx *c, int depth);
+
+// frame planner (slab.hip)
+void plan_update_a(fs_ctx *c);          // update() up to subtractGradient (+ the CFL reduction on slabs)
+void plan_update_b(fs_ctx *c, int h);   // advection .. particles, with advection halo h
+int exec_step(fs_ctx *c, const Step &s);
+int run_frame(fs_ctx *c);               // plan + execute one update() on this context (world 1 or RCCL)
+int comm_exchange(fs_ctx *c, const std::vector<Xfer> &xf);
+int comm_allreduce_max(fs_ctx *c);
+
+}  // namespace fs
+
+#define CTX(c)                                             \
+    do {                                                   \
+        if (!(c)) { fs::set_error("ctx is NULL"); return FS_ERR_INVALID; } \
+        hipError_t e_ = hipSetDevice((c)->device);         \
+        if (e_ != hipSuccess) return fs::ctx_fail(c, fs::hip_fail(e_, "hipSetDevice")); \
+    } while (0)
+#define TRY(c, call)                        \
+    do {                                    \
+        int rc_ = (call);                   \
+        if (rc_) return fs::ctx_fail(c, rc_);   \
+    } while (0)
+#define TRYHIP(c, call)                                            \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return fs::ctx_fail(c, fs::hip_fail(e_, #call)); \
+    } while (0)

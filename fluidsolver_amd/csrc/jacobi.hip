@@ -251,6 +251,13 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
     return FS_OK;
 }
 
+// launches run_sweeps makes for n sweeps (the frame planner needs the ping-pong parity ahead of time)
+int jacobi_launch_count(int op, int n)
+{
+    const int maxT = g_block_depth[op == 1 ? 1 : 0];
+    return n <= 0 ? 0 : (n + maxT - 1) / maxT;
+}
+
 int config_set_block_depth(int op, int v)   // op < 0: both loops
 {
     if (v < 1 || v > 48 || op > 1) return FS_ERR_INVALID;

@@ -1,0 +1,745 @@
+// slab.hip -- frame planner of update() (Solver:477-627) for a row slab, and the halo transports.
+//
+// The reference has one GPU and no communication (Solver:269); this layer is new work whose contract
+// is SURVEY.md 8(e):
+//   * GPU g owns the contiguous rows [r0, r1) and all columns; its buffers also hold up to G ghost
+//     rows on each interior side, so halo rows are contiguous in memory.
+//   * Every stage is the SAME fs_k_* kernel the single-GPU path runs, launched on a row range, so a
+//     k-slab run equals the 1-GPU run bit for bit.
+//   * Ghost rows are not refreshed after every stencil.  Each field carries a valid depth; a radius-1
+//     stencil computed on the owned rows +- d consumes one row of depth.  Exchanges are planned lazily:
+//     one round of velocity at frame start (2N+3 rows for vorticity -> N diffuse sweeps -> divergence
+//     -> N pressure sweeps -> gradient) and one of velocity + dye before advection.  xGMI halo traffic
+//     is latency-bound (a 16384-column row is 64 KiB ~ 0.4 us of wire time), so two rounds per frame
+//     beat one per sweep, and the redundant ghost-row compute is cheap.
+//   * The semi-Lagrangian backtrace is clamped only to the domain (Shaders:133-137), so the advection
+//     halo is sized per frame from the CFL bound: h = ceil(max|v_y| dt) + 2, max over all ranks (one
+//     4-byte all-reduce + one host sync per frame).
+//
+// A frame is first PLANNED (pure host bookkeeping of ghost depths and ping-pong roles; identical on
+// every rank) into a list of steps -- kernel launches, exchanges, the CFL reduction -- then executed.
+// On one GPU the plan has no exchange and the whole list is captured as a hipGraph (context.hip).
+// With RCCL a rank walks its list; an in-process group (tests) walks K lists in lock step.
+// fluidsolver_amd/slabs.py is the same planner in Python (executable specification, tested on the CPU
+// under gloo against the unsplit oracle); tests compare the two plans line by line.
+#include "ctx.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace fs {
+
+int jacobi_launch_count(int op, int n);   // jacobi.hip
+
+void slab_rows(int H, int world, int rank, int *r0, int *r1)
+{
+    const int base = H / world, rem = H % world;   // the first H % world ranks own one extra row
+    *r0 = rank * base + std::min(rank, rem);
+    *r1 = *r0 + base + (rank < rem ? 1 : 0);
+}
+
+// fs_grid computing the owned rows +- depth (clipped to the buffer, hence to the domain)
+fs_grid grid_of(const fs_ctx *c, int depth)
+{
+    depth = std::min(depth, c->G);
+    const int yb = std::max(c->b0, c->r0 - depth), ye = std::min(c->b1, c->r1 + depth);
+    return fs_grid{c->W, c->H, c->pitch, c->b0, c->b1 - c->b0, yb, ye};
+}
+
+namespace {
+
+struct Planner {
+    fs_ctx *c;
+    const bool multi;
+    const int G;
+    explicit Planner(fs_ctx *ctx) : c(ctx), multi(ctx->world > 1), G(ctx->G) {}
+
+    int eff(int f) const { return std::min(c->f[f].valid, G); }   // usable depth: valid AND present in the buffer
+
+    void compute(const char *what, const fs_grid &g, int n, std::function<int()> fn)
+    {
+        Step s;
+        s.kind = STEP_COMPUTE;
+        s.what = what;
+        s.yb = g.yb; s.ye = g.ye; s.n = n;
+        s.run = std::move(fn);
+        c->steps.push_back(std::move(s));
+    }
+
+    // refresh, in ONE batched round, every listed field whose valid depth is short (capped at G)
+    void ensure(std::initializer_list<std::pair<int, int>> wants)
+    {
+        if (!multi) return;
+        Step s;
+        s.kind = STEP_EXCHANGE;
+        s.what = "exchange";
+        for (const auto &w : wants) {
+            const int d = std::min(w.second, G);
+            if (c->f[w.first].valid < d) s.xf.push_back(Xfer{w.first, c->f[w.first].cur, d});
+        }
+        if (s.xf.empty()) return;
+        for (const auto &x : s.xf) c->f[x.field].valid = x.depth;
+        c->steps.push_back(std::move(s));
+    }
+    void need(int f, int depth)
+    {
+        if (multi && c->f[f].valid < std::min(depth, G)) ensure({{f, depth}});
+    }
+
+    // N Jacobi sweeps on field fi (ping-pong).  One sweep computed on the owned rows +- d reads the
+    // previous iterate on +- (d+1), i.e. consumes one row of ghost depth.  The sweeps run in as few
+    // temporally blocked chunks as the available depth allows; ghosts are re-exchanged only when the
+    // depth is used up.
+    void sweeps(bool pressure, int fi, int N, int need_out)
+    {
+        Field &F = c->f[fi];
+        int remaining = N;
+        while (remaining > 0) {
+            int n, out_depth;
+            if (!multi) {
+                n = remaining;
+                out_depth = 0;
+            } else {
+                const int want = need_out + remaining;   // depth that finishes the loop with no further exchange
+                if (F.valid < 1) ensure({{fi, want}});
+                const int a = std::min(F.valid, G);
+                if (a >= want) { n = remaining; out_depth = need_out; }
+                else { n = std::min(remaining, a); out_depth = a - n; }
+                if (pressure) {
+                    // the sweep at depth d reads div at depth d; the deepest sweep of the chunk is out_depth + n - 1
+                    Field &D = c->f[F_DIV];
+                    if (D.valid < out_depth + n - 1) ensure({{F_DIV, need_out + remaining - 1}});
+                    const int vd = std::min(D.valid, G);
+                    if (vd < out_depth + n - 1) {
+                        n = std::min(n, vd + 1);
+                        out_depth = std::min(out_depth, vd - (n - 1));
+                    }
+                }
+            }
+            const fs_grid g = grid_of(c, out_depth);
+            float *src = F.p(), *dst = F.t();
+            hipStream_t st = c->stream;
+            if (pressure) {
+                const int pz = c->p_zero ? 1 : 0;
+                c->p_zero = false;
+                const float *div = c->f[F_DIV].p();
+                compute("pressure_n", g, n, [=]() {                                   // Solver:533-541
+                    int ib = 0;
+                    return fs_k_pressureSolve_n(&g, div, src, dst, n, pz, &ib, st);
+                });
+            } else {
+                const float coeff = fi == F_VEL ? c->params.viscosity : c->params.diffusion;
+                const float dt = c->params.deltaTime;
+                const int np = F.np;
+                const size_t plane = c->plane;
+                compute("diffuse_n", g, n, [=]() {                                    // Solver:506-517, :563-573
+                    int ib = 0;
+                    return fs_k_diffuse_n(&g, src, dst, np, plane, coeff, dt, n, &ib, st);
+                });
+            }
+            if (jacobi_launch_count(pressure ? 0 : 1, n) & 1) F.cur ^= 1;
+            if (multi) F.valid = out_depth;
+            remaining -= n;
+        }
+    }
+
+    void advect(int fi, bool fade)
+    {
+        Field &F = c->f[fi];
+        const fs_grid g = grid_of(c, 0);
+        const float *u = c->f[F_VEL].p(), *v = u + c->plane;
+        const float *src = F.p();
+        float *dst = F.t();
+        const int np = F.np;
+        const size_t plane = c->plane;
+        const float dt = c->params.deltaTime, fr = c->params.fadeSpeed;
+        int *err = c->err_flag;
+        hipStream_t st = c->stream;
+        if (fade)
+            compute("advect_fade", g, np, [=]() { return fs_k_advect_fade(&g, u, v, src, dst, np, plane, dt, fr, err, st); });
+        else
+            compute("advect", g, np, [=]() { return fs_k_advect(&g, u, v, src, dst, np, plane, dt, err, st); });
+        F.cur ^= 1;                                                                   // Solver:558, :584
+        if (multi) F.valid = 0;
+    }
+
+    // update() up to subtractGradient, Solver:486-547
+    void plan_a()
+    {
+        const fs_params &p = c->params;
+        const int N = p.solverIterations;
+        const float dt = p.deltaTime;
+        const bool vort_on = p.vorticityStrength > 0.0f, visc_on = p.viscosity > 0.0f;
+        hipStream_t st = c->stream;
+        const size_t plane = c->plane;
+        // ghost depths the velocity chain needs, backwards from subtractGradient on the owned rows:
+        // p(1) <- N sweeps <- div(N) <- vel(N+1) <- N diffuse sweeps <- vel(2N+1) <- applyVorticity
+        // <- vort(2N+2) <- vel(2N+3)
+        const int need_p = 1;
+        const int need_div = need_p + std::max(N - 1, 0);
+        const int need_v2 = need_div + 1;
+        const int need_v1 = need_v2 + (visc_on ? N : 0);
+        const int need_v0 = need_v1 + (vort_on ? 2 : 0);
+        Field &V = c->f[F_VEL];
+
+        if (vort_on) {                                                                // :486-502
+            need(F_VEL, need_v0);
+            const int dw = multi ? std::min(need_v1 + 1, eff(F_VEL) - 1) : 0;
+            {
+                const fs_grid g = grid_of(c, dw);
+                float *u = V.p(), *v = u + plane, *w = c->f[F_VORT].p();
+                compute("vorticity", g, 0, [=]() { return fs_k_calculateVorticity(&g, u, v, w, st); });   // :488-491
+            }
+            const int dv = multi ? std::min(std::min(need_v1, dw - 1), eff(F_VEL)) : 0;
+            {
+                const fs_grid g = grid_of(c, dv);
+                float *u = V.p(), *v = u + plane, *w = c->f[F_VORT].p();
+                const float strength = p.vorticityStrength;
+                compute("applyVorticity", g, 0, [=]() { return fs_k_applyVorticity(&g, w, u, v, strength, dt, st); });   // :494-501
+            }
+            if (multi) { c->f[F_VORT].valid = dw; V.valid = dv; }
+        }
+        if (visc_on && N > 0) {                                                       // :505-518
+            need(F_VEL, need_v1);
+            sweeps(false, F_VEL, N, need_v2);
+        }
+        need(F_VEL, need_v2);
+        const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
+        {
+            const fs_grid g = grid_of(c, dd);
+            float *u = V.p(), *v = u + plane, *d = c->f[F_DIV].p();
+            compute("divergence", g, 0, [=]() { return fs_k_divergence(&g, u, v, d, st); });              // :522-525
+        }
+        if (multi) c->f[F_DIV].valid = dd;
+        c->p_zero = true;                                                             // clear folded in, :528-530
+        c->f[F_P].valid = kInf;
+        if (N > 0) {
+            sweeps(true, F_P, N, need_p);                                             // :533-541
+        } else {
+            const fs_grid g = grid_of(c, G);
+            float *pp = c->f[F_P].p();
+            compute("clear", g, 0, [=]() { return fs_k_clear(&g, pp, 1, 0, st); });
+            c->p_zero = false;
+        }
+        need(F_P, 1);
+        {
+            const fs_grid g = grid_of(c, 0);
+            float *u = V.p(), *v = u + plane, *pp = c->f[F_P].p();
+            compute("subtractGradient", g, 0, [=]() { return fs_k_subtractGradient(&g, pp, u, v, st); }); // :544-547
+        }
+        if (multi) {
+            V.valid = 0;
+            // CFL bound of the backtrace: max |v_y| over the owned rows, then max over ranks
+            const fs_grid g = grid_of(c, 0);
+            float *v = V.p() + plane, *cfl = c->cfl_dev;
+            compute("max_abs", g, 0, [=]() {
+                hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
+                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
+                return fs_k_max_abs(&g, v, cfl, st);
+            });
+            Step s;
+            s.kind = STEP_CFL_REDUCE;
+            s.what = "cfl_allreduce";
+            c->steps.push_back(std::move(s));
+        }
+    }
+
+    // advection .. tracers, Solver:550-623, with advection halo h (0 on one GPU)
+    void plan_b(int h)
+    {
+        const fs_params &p = c->params;
+        const int N = p.solverIterations;
+        const int ddn = (p.diffusion > 0.0f && N > 0) ? N : 0;
+        hipStream_t st = c->stream;
+        const size_t plane = c->plane;
+        if (multi) ensure({{F_VEL, h}, {F_DYE, h + ddn}});                            // one batched round
+        advect(F_VEL, false);                                                         // :550-558
+        if (ddn) {                                                                    // :562-574
+            sweeps(false, F_DYE, N, h);
+            need(F_DYE, h);
+        }
+        if (c->fuse) {
+            advect(F_DYE, true);                                                      // :577-591 in one pass
+        } else {
+            advect(F_DYE, false);                                                     // :577-584
+            const fs_grid g = grid_of(c, 0);
+            float *d = c->f[F_DYE].p();
+            const float fr = p.fadeSpeed;
+            compute("fade", g, 0, [=]() { return fs_k_fadeDensity(&g, d, 3, plane, fr, st); });           // :587-591
+        }
+        if (multi) c->f[F_DYE].valid = 0;
+        // render, :594-623
+        {
+            const fs_grid g = grid_of(c, 0);
+            float *u = c->f[F_VEL].p(), *v = u + plane, *d = c->f[F_DYE].p(), *w = c->f[F_VORT].p(), *disp = c->display;
+            const float br = p.brightness;
+            switch (p.displayMode) {
+            case FS_DISPLAY_DENSITY:
+                compute("render", g, 0, [=]() { return fs_k_renderDensity(&g, d, plane, 3, disp, plane, br, st); });
+                break;
+            case FS_DISPLAY_VELOCITY:
+                compute("render", g, 0, [=]() { return fs_k_renderVelocity(&g, u, v, disp, plane, 1.0f, st); });
+                break;
+            case FS_DISPLAY_SPEED:
+                compute("render", g, 0, [=]() { return fs_k_renderSpeed(&g, u, v, disp, plane, 25.0f, st); });
+                break;
+            case FS_DISPLAY_VORTICITY:
+                compute("render", g, 0, [=]() { return fs_k_renderDensity(&g, w, plane, 1, disp, plane, 10.0f, st); });
+                break;
+            case FS_DISPLAY_PARTICLES_ONLY:
+                compute("render", g, 0, [=]() { return fs_k_clear(&g, disp, 4, plane, st); });
+                break;
+            default: break;   // FS_DISPLAY_NONE: headless
+            }
+        }
+        if (c->with_particles && c->n_particles > 0 && !multi) {                      // MetalView.swift:155 -> Part:242
+            const fs_grid g = grid_of(c, 0);
+            float *u = c->f[F_VEL].p(), *v = u + plane;
+            const fs_particle_params pp = c->pparams;
+            const long n = c->n_particles;
+            float *a0 = c->part[0], *a1 = c->part[1], *a2 = c->part[2], *a3 = c->part[3], *a4 = c->part[4],
+                  *a5 = c->part[5], *a6 = c->part[6];
+            compute("particles", g, 0, [=]() { return fs_k_particles_update(&g, u, v, &pp, n, a0, a1, a2, a3, a4, a5, a6, st); });
+        }
+    }
+};
+
+// ---- RCCL, resolved at run time so that single-GPU hosts need no librccl ------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return FS_OK;
+    void *h = nullptr;
+    // a copy already in the process (e.g. the one PyTorch ships) wins, so one RCCL serves the process
+    const char *loaded[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : loaded)
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char *env = getenv("FS_RCCL_LIBRARY");
+    if (!h && env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    const char *paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : paths)
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { set_error("cannot load librccl (%s); set FS_RCCL_LIBRARY", dlerror()); return FS_ERR_STATE; }
+#define SYM(field, name)                                                                  \
+    do {                                                                                  \
+        *(void **)(&g_rccl.field) = dlsym(h, name);                                       \
+        if (!g_rccl.field) { set_error("librccl lacks %s", name); return FS_ERR_STATE; }  \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.handle = h;
+    return FS_OK;
+}
+
+int rccl_fail(ncclResult_t r, const char *what)
+{
+    set_error("RCCL error %d (%s) in %s", (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", what);
+    return FS_ERR_HIP;
+}
+#define FS_NCCL(call)                                       \
+    do {                                                    \
+        ncclResult_t r_ = (call);                           \
+        if (r_ != ncclSuccess) return rccl_fail(r_, #call); \
+    } while (0)
+
+// One contiguous block of rows of one plane that moves between two ranks.
+struct Seg {
+    int peer, field, bufidx, plane, y0, y1;
+    bool send;
+};
+
+// Rows a rank with owned rows [q0,q1) needs for ghost depth d: [max(0,q0-d), q0) and [q1, min(H,q1+d)).
+// Every other rank that owns part of them sends that part (single hop when d <= its slab height,
+// multi hop otherwise).  Sends to a peer are generated in the order the peer generates its receives.
+void build_segments(const fs_ctx *c, const std::vector<Xfer> &xf, std::vector<Seg> &out)
+{
+    for (const Xfer &x : xf) {
+        const int d = x.depth, np = c->f[x.field].np;
+        for (int q = 0; q < c->world; ++q) {
+            if (q == c->rank) continue;
+            int q0, q1;
+            slab_rows(c->H, c->world, q, &q0, &q1);
+            const int mine[2][2] = {{std::max(0, c->r0 - d), c->r0}, {c->r1, std::min(c->H, c->r1 + d)}};
+            const int theirs[2][2] = {{std::max(0, q0 - d), q0}, {q1, std::min(c->H, q1 + d)}};
+            for (int k = 0; k < 2; ++k) {   // what I receive from q
+                const int a = std::max(mine[k][0], q0), b = std::min(mine[k][1], q1);
+                for (int pl = 0; a < b && pl < np; ++pl) out.push_back(Seg{q, x.field, x.bufidx, pl, a, b, false});
+            }
+            for (int k = 0; k < 2; ++k) {   // what I send to q
+                const int a = std::max(theirs[k][0], c->r0), b = std::min(theirs[k][1], c->r1);
+                for (int pl = 0; a < b && pl < np; ++pl) out.push_back(Seg{q, x.field, x.bufidx, pl, a, b, true});
+            }
+        }
+    }
+}
+
+float *seg_ptr(const fs_ctx *c, const Seg &s)
+{
+    return c->f[s.field].buf[s.bufidx] + (size_t)s.plane * c->plane + (size_t)(s.y0 - c->b0) * c->pitch;
+}
+
+int sync_members(const fs_comm *cm)
+{
+    for (fs_ctx *m : cm->members) {
+        if (!m) { set_error("local group: a rank has no context yet"); return FS_ERR_STATE; }
+        FS_HIP(hipSetDevice(m->device));
+        FS_HIP(hipStreamSynchronize(m->stream));
+    }
+    return FS_OK;
+}
+
+}  // namespace
+
+void plan_update_a(fs_ctx *c) { Planner(c).plan_a(); }
+void plan_update_b(fs_ctx *c, int h) { Planner(c).plan_b(h); }
+
+int comm_exchange(fs_ctx *c, const std::vector<Xfer> &xf)
+{
+    fs_comm *cm = c->comm;
+    if (!cm) { set_error("exchange planned on a context without a communicator"); return FS_ERR_STATE; }
+    std::vector<Seg> segs;
+    build_segments(c, xf, segs);
+    c->stat_exchanges += 1;
+    for (const Seg &s : segs)
+        if (s.send) c->stat_rows += s.y1 - s.y0;
+    if (cm->kind == 1) {
+        FS_NCCL(g_rccl.GroupStart());
+        for (const Seg &s : segs) {
+            const size_t count = (size_t)(s.y1 - s.y0) * c->pitch;
+            ncclResult_t r = s.send ? g_rccl.Send(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->stream)
+                                    : g_rccl.Recv(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->stream);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(r, s.send ? "ncclSend" : "ncclRecv"); }
+        }
+        FS_NCCL(g_rccl.GroupEnd());
+        return FS_OK;
+    }
+    // in-process group: every rank's owned rows are final when its turn comes (lock step), ghost rows
+    // are only written here; plain blocking copies between full synchronisations
+    int rc = sync_members(cm);
+    if (rc) return rc;
+    FS_HIP(hipSetDevice(c->device));
+    for (const Seg &s : segs) {
+        if (s.send) continue;
+        const fs_ctx *peer = cm->members[s.peer];
+        FS_HIP(hipMemcpy(seg_ptr(c, s), seg_ptr(peer, s), (size_t)(s.y1 - s.y0) * c->pitch * sizeof(float),
+                         hipMemcpyDeviceToDevice));
+    }
+    FS_HIP(hipDeviceSynchronize());
+    return FS_OK;
+}
+
+int comm_allreduce_max(fs_ctx *c)
+{
+    fs_comm *cm = c->comm;
+    if (!cm) { set_error("CFL reduction planned on a context without a communicator"); return FS_ERR_STATE; }
+    if (cm->kind == 1) {
+        FS_NCCL(g_rccl.AllReduce(c->cfl_dev, c->cfl_dev, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, c->stream));
+        FS_HIP(hipMemcpyAsync(c->cfl_host, c->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        c->cfl_max = *c->cfl_host;
+        return FS_OK;
+    }
+    int rc = sync_members(cm);
+    if (rc) return rc;
+    float m = 0.0f;
+    for (fs_ctx *x : cm->members) {
+        float v = 0.0f;
+        FS_HIP(hipSetDevice(x->device));
+        FS_HIP(hipMemcpy(&v, x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost));
+        if (!(v <= m)) m = v;   // NaN propagates
+    }
+    FS_HIP(hipSetDevice(c->device));
+    c->cfl_max = m;
+    return FS_OK;
+}
+
+int exec_step(fs_ctx *c, const Step &s)
+{
+    switch (s.kind) {
+    case STEP_COMPUTE: return s.run();
+    case STEP_EXCHANGE: return comm_exchange(c, s.xf);
+    case STEP_CFL_REDUCE: return comm_allreduce_max(c);
+    }
+    return FS_ERR_STATE;
+}
+
+// bilinear taps lie within ceil(|v_y| dt) + 1 rows; +1 more because the dye is traced through the
+// ADVECTED velocity, whose fp32 mix() can exceed the old maximum by rounding only
+static int halo_from_cfl(fs_ctx *c, int *h)
+{
+    const double reach = (double)c->cfl_max * std::fabs((double)c->params.deltaTime);
+    if (!(reach < 1.0e9)) {
+        set_error("velocity is not finite (max |v_y| = %g): cannot size the advection halo", (double)c->cfl_max);
+        return FS_ERR_HALO;
+    }
+    *h = (int)std::ceil(reach) + 2;
+    c->last_halo = *h;
+    if (*h > c->G) {
+        set_error("advection halo of %d rows (max |v_y| dt = %.1f) exceeds the ghost capacity of %d rows; create the "
+                  "slabs with more ghost rows", *h, reach, c->G);
+        return FS_ERR_HALO;
+    }
+    return FS_OK;
+}
+
+int run_frame(fs_ctx *c)
+{
+    c->steps.clear();
+    plan_update_a(c);
+    int rc;
+    for (const Step &s : c->steps)
+        if ((rc = exec_step(c, s))) return rc;
+    int h = 0;
+    if (c->world > 1 && (rc = halo_from_cfl(c, &h))) return rc;
+    c->steps.clear();
+    plan_update_b(c, h);
+    for (const Step &s : c->steps)
+        if ((rc = exec_step(c, s))) return rc;
+    c->steps.clear();
+    c->stat_frames += 1;
+    return FS_OK;
+}
+
+static void append_plan(const fs_ctx *c, std::string &out)
+{
+    static const char *names[F_COUNT] = {"vel", "dye", "p", "div", "vort"};
+    char line[160];
+    for (const Step &s : c->steps) {
+        if (s.kind == STEP_COMPUTE) {
+            snprintf(line, sizeof(line), "%s %d %d %d\n", s.what, s.yb, s.ye, s.n);
+            out += line;
+        } else if (s.kind == STEP_EXCHANGE) {
+            out += "exchange";
+            for (const Xfer &x : s.xf) {
+                snprintf(line, sizeof(line), " %s:%d", names[x.field], x.depth);
+                out += line;
+            }
+            out += "\n";
+        } else {
+            out += "cfl_allreduce\n";
+        }
+    }
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+int create_common(int width, int height, int device, fs_comm *comm, int world, int rank, int ghost_rows,
+                  long max_particles, bool dry, fs_ctx **out);   // context.hip
+
+extern "C" {
+
+int fs_comm_unique_id(void *id128)
+{
+    if (!id128) { set_error("fs_comm_unique_id: NULL buffer"); return FS_ERR_INVALID; }
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == FS_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    FS_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return FS_OK;
+}
+
+int fs_comm_create_rccl(int world, int rank, int device, const void *id128, fs_comm **out)
+{
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("fs_comm_create_rccl: bad arguments"); return FS_ERR_INVALID; }
+    *out = nullptr;
+    int rc = load_rccl();
+    if (rc) return rc;
+    FS_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t nc = nullptr;
+    FS_NCCL(g_rccl.CommInitRank(&nc, world, id, rank));
+    fs_comm *cm = new (std::nothrow) fs_comm();
+    if (!cm) { (void)g_rccl.CommDestroy(nc); return FS_ERR_NOMEM; }
+    cm->kind = 1; cm->world = world; cm->rank = rank; cm->device = device; cm->nccl = nc;
+    *out = cm;
+    return FS_OK;
+}
+
+int fs_comm_create_local(int world, fs_comm **out)
+{
+    if (!out || world < 1 || world > 1024) { set_error("fs_comm_create_local: bad arguments"); return FS_ERR_INVALID; }
+    fs_comm *cm = new (std::nothrow) fs_comm();
+    if (!cm) return FS_ERR_NOMEM;
+    cm->kind = 0; cm->world = world;
+    cm->members.assign(world, nullptr);
+    *out = cm;
+    return FS_OK;
+}
+
+int fs_comm_destroy(fs_comm *cm)
+{
+    if (!cm) return FS_OK;
+    if (cm->kind == 1 && cm->nccl && g_rccl.CommDestroy) {
+        (void)hipSetDevice(cm->device);
+        (void)g_rccl.CommDestroy((ncclComm_t)cm->nccl);
+    }
+    delete cm;
+    return FS_OK;
+}
+
+// Round trip through the transport: a grouped ncclSend/ncclRecv of `count` floats to the next rank
+// and from the previous one (to itself when world == 1) and a 1-float all-reduce(max).
+int fs_comm_selftest(fs_comm *cm, int count)
+{
+    if (!cm || cm->kind != 1 || count < 1) { set_error("fs_comm_selftest: needs an RCCL communicator"); return FS_ERR_INVALID; }
+    FS_HIP(hipSetDevice(cm->device));
+    const int next = (cm->rank + 1) % cm->world, prev = (cm->rank + cm->world - 1) % cm->world;
+    std::vector<float> h(count), back(count);
+    for (int i = 0; i < count; ++i) h[i] = (float)(cm->rank * 1000003 + i);
+    float *src = nullptr, *dst = nullptr, *red = nullptr;
+    hipStream_t st = nullptr;
+    int rc = FS_OK;
+    hipError_t e;
+    float mine = (float)(cm->rank + 1), got = 0.0f;
+#define ST_HIP(call) do { if (!rc && (e = (call)) != hipSuccess) rc = hip_fail(e, #call); } while (0)
+#define ST_NCCL(call) do { ncclResult_t r_; if (!rc && (r_ = (call)) != ncclSuccess) rc = rccl_fail(r_, #call); } while (0)
+    ST_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ST_HIP(hipMalloc((void **)&src, count * sizeof(float)));
+    ST_HIP(hipMalloc((void **)&dst, count * sizeof(float)));
+    ST_HIP(hipMalloc((void **)&red, sizeof(float)));
+    ST_HIP(hipMemcpy(src, h.data(), count * sizeof(float), hipMemcpyHostToDevice));
+    ST_HIP(hipMemset(dst, 0, count * sizeof(float)));
+    ST_HIP(hipMemcpy(red, &mine, sizeof(float), hipMemcpyHostToDevice));
+    ST_NCCL(g_rccl.GroupStart());
+    ST_NCCL(g_rccl.Send(src, count, ncclFloat, next, (ncclComm_t)cm->nccl, st));
+    ST_NCCL(g_rccl.Recv(dst, count, ncclFloat, prev, (ncclComm_t)cm->nccl, st));
+    ST_NCCL(g_rccl.GroupEnd());
+    ST_NCCL(g_rccl.AllReduce(red, red, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, st));
+    ST_HIP(hipStreamSynchronize(st));
+    ST_HIP(hipMemcpy(back.data(), dst, count * sizeof(float), hipMemcpyDeviceToHost));
+    ST_HIP(hipMemcpy(&got, red, sizeof(float), hipMemcpyDeviceToHost));
+#undef ST_HIP
+#undef ST_NCCL
+    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(red);
+    if (st) (void)hipStreamDestroy(st);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i)
+        if (back[i] != (float)(prev * 1000003 + i)) { set_error("fs_comm_selftest: element %d arrived as %g", i, (double)back[i]); return FS_ERR_STATE; }
+    if (got != (float)cm->world) { set_error("fs_comm_selftest: all-reduce(max) gave %g, expected %d", (double)got, cm->world); return FS_ERR_STATE; }
+    return FS_OK;
+}
+
+int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out)
+{
+    if (!comm) { set_error("fs_create_slab: communicator is NULL"); return FS_ERR_INVALID; }
+    if (comm->kind == 1) rank = comm->rank;
+    if (rank < 0 || rank >= comm->world) { set_error("fs_create_slab: rank %d of %d", rank, comm->world); return FS_ERR_INVALID; }
+    if (comm->kind == 1 && device != comm->device) { set_error("fs_create_slab: the communicator lives on device %d", comm->device); return FS_ERR_INVALID; }
+    if (comm->kind == 0 && comm->members[rank]) { set_error("fs_create_slab: rank %d already exists in this group", rank); return FS_ERR_INVALID; }
+    int rc = create_common(width, height, device, comm, comm->world, rank, ghost_rows, 0, false, out);
+    if (!rc && comm->kind == 0) comm->members[rank] = *out;
+    return rc;
+}
+
+int fs_slab_info(fs_ctx *c, int info[6])
+{
+    if (!c || !info) return FS_ERR_INVALID;
+    info[0] = c->r0; info[1] = c->r1; info[2] = c->b0; info[3] = c->b1; info[4] = c->G; info[5] = c->last_halo;
+    return FS_OK;
+}
+
+int fs_slab_stats(fs_ctx *c, long stats[3])
+{
+    if (!c || !stats) return FS_ERR_INVALID;
+    stats[0] = c->stat_exchanges; stats[1] = c->stat_rows; stats[2] = c->stat_frames;
+    return FS_OK;
+}
+
+// One update() on every slab of an in-process group, in lock step: step i of every rank runs before
+// step i+1 of any, which is the ordering the exchanges of a real multi-process run enforce.
+int fs_group_step(fs_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->comm || ctxs[0]->comm->kind != 0 || ctxs[0]->comm->world != n) {
+        set_error("fs_group_step: needs all %d contexts of one local group, in rank order", n);
+        return FS_ERR_INVALID;
+    }
+    for (int r = 0; r < n; ++r)
+        if (!ctxs[r] || ctxs[r]->comm != ctxs[0]->comm || ctxs[r]->rank != r) {
+            set_error("fs_group_step: context %d is not rank %d of the group", r, r);
+            return FS_ERR_INVALID;
+        }
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int r = 0; r < n; ++r) {
+            fs_ctx *c = ctxs[r];
+            c->steps.clear();
+            if (phase == 0) {
+                plan_update_a(c);
+            } else {
+                int h = 0;
+                if (n > 1) TRY(c, halo_from_cfl(c, &h));
+                plan_update_b(c, h);
+            }
+            if (c->steps.size() != ctxs[0]->steps.size()) {
+                set_error("fs_group_step: rank %d planned %zu steps, rank 0 %zu", r, c->steps.size(), ctxs[0]->steps.size());
+                return ctx_fail(c, FS_ERR_STATE);
+            }
+        }
+        for (size_t i = 0; i < ctxs[0]->steps.size(); ++i)
+            for (int r = 0; r < n; ++r) {
+                fs_ctx *c = ctxs[r];
+                CTX(c);
+                TRY(c, exec_step(c, c->steps[i]));
+            }
+    }
+    for (int r = 0; r < n; ++r) { ctxs[r]->steps.clear(); ctxs[r]->stat_frames += 1; }
+    return FS_OK;
+}
+
+// Host-only: the frame plans of `frames` consecutive update() calls of one rank, as text (one step per
+// line: "<stage> <yb> <ye> <n>", "exchange <field>:<depth> ...", "cfl_allreduce"), with the advection
+// halo of frame f given by halos[f].  No GPU is touched.  Tests compare it with the Python planner.
+int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, const fs_params *p, int frames,
+                      const int *halos, char *buf, size_t cap)
+{
+    if (!p || !buf || cap < 1 || frames < 0 || (frames > 0 && world > 1 && !halos)) { set_error("fs_slab_plan_dump: bad arguments"); return FS_ERR_INVALID; }
+    fs_ctx *c = nullptr;
+    int rc = create_common(width, height, 0, nullptr, world, rank, ghost_rows, 0, true, &c);
+    if (rc) return rc;
+    c->params = *p;
+    std::string out;
+    for (int f = 0; f < frames; ++f) {
+        c->steps.clear();
+        plan_update_a(c);
+        append_plan(c, out);
+        c->steps.clear();
+        plan_update_b(c, world > 1 ? halos[f] : 0);
+        append_plan(c, out);
+    }
+    c->steps.clear();
+    delete c;
+    if (out.size() + 1 > cap) { set_error("fs_slab_plan_dump: buffer of %zu bytes is too small for %zu", cap, out.size() + 1); return FS_ERR_INVALID; }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return FS_OK;
+}
+
+}  // extern "C"

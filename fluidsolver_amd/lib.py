@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfluidsolver_hip.so")
 
 FS_OK = 0
+COMM_ID_BYTES = 128
 ERRORS = {-1: "FS_ERR_INVALID", -2: "FS_ERR_HIP", -3: "FS_ERR_NOMEM", -4: "FS_ERR_HALO", -5: "FS_ERR_STATE"}
 
 FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE, FIELD_VORTICITY, FIELD_DISPLAY = range(6)
@@ -97,6 +98,16 @@ SIGNATURES = {
     "fs_default_particle_params": (_i, [C.POINTER(ParticleParams), _f, _f]),
     "fs_particles_update": (_i, [_p, C.POINTER(ParticleParams)]),
     "fs_particles_count": (_l, [_p]),
+    "fs_comm_unique_id": (_i, [_p]),
+    "fs_comm_create_rccl": (_i, [_i, _i, _i, _p, C.POINTER(_p)]),
+    "fs_comm_create_local": (_i, [_i, C.POINTER(_p)]),
+    "fs_comm_destroy": (_i, [_p]),
+    "fs_comm_selftest": (_i, [_p, _i]),
+    "fs_create_slab": (_i, [_i, _i, _i, _p, _i, _i, C.POINTER(_p)]),
+    "fs_slab_info": (_i, [_p, C.POINTER(_i)]),
+    "fs_slab_stats": (_i, [_p, C.POINTER(_l)]),
+    "fs_group_step": (_i, [C.POINTER(_p), _i]),
+    "fs_slab_plan_dump": (_i, [_i, _i, _i, _i, _i, C.POINTER(Params), _i, C.POINTER(_i), C.c_char_p, _sz]),
     "fs_last_error": (C.c_char_p, [_p]),
     "fs_version": (C.c_char_p, []),
     "fs_selftest_divide": (_i, [_f, C.POINTER(C.c_ulonglong)]),

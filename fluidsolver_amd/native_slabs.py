@@ -1,0 +1,177 @@
+"""Host side of the native row-slab path (layer 3 of include/fluidsolver.h): the frame planner, the
+kernels and the RCCL halo exchange all live in libfluidsolver_hip.so; this file only creates the
+communicator and forwards calls.
+
+    RcclSlab   one rank of a multi-process run (one process per GPU; launched by torch.distributed.run).
+               The 128-byte RCCL unique id travels from rank 0 over an already initialised
+               torch.distributed group (any backend) -- the control plane; halo rows never touch torch.
+    LocalGroup all K slabs in this process (tests on a 1-GPU box), stepped in lock step.
+
+The reference has one GPU and no counterpart (FluidSolver.swift:269).  slabs.py holds the same
+planner in Python as an executable specification; tests/test_slab_plan.py compares the two.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from .script import splat
+
+F = np.float32
+FIELDS = {"vel": L.FIELD_VELOCITY, "dye": L.FIELD_DENSITY, "p": L.FIELD_PRESSURE, "div": L.FIELD_DIVERGENCE,
+          "vort": L.FIELD_VORTICITY}
+
+
+def make_params(params, display=L.DISPLAY_NONE, brightness=0.06):
+    """params = (viscosity, diffusion, deltaTime, vorticityStrength, fadeSpeed, solverIterations)."""
+    v, d, dt, vs, fade, n = params
+    return L.Params(v, d, dt, vs, fade, int(n), display, brightness)
+
+
+def plan_dump(W, H, world, rank, ghost, params, halos):
+    """Text of the frame plans of len(halos) consecutive update() calls (host only, no GPU)."""
+    lib = L.load()
+    p = make_params(params)
+    hs = (C.c_int * max(1, len(halos)))(*halos)
+    buf = C.create_string_buffer(1 << 20)
+    L.check(lib.fs_slab_plan_dump(W, H, world, rank, -1 if ghost is None else int(ghost), C.byref(p), len(halos), hs,
+                                  buf, len(buf)))
+    return buf.value.decode()
+
+
+class _Slab:
+    """One fs_ctx created by fs_create_slab."""
+
+    def __init__(self, W, H, params, device, comm, rank, ghost, radius=5.0):
+        self.lib = L.load()
+        self.W, self.H = int(W), int(H)
+        self.radius = float(radius)
+        self.deltaTime = float(params[2])
+        ctx = C.c_void_p()
+        L.check(self.lib.fs_create_slab(self.W, self.H, int(device), comm, int(rank), -1 if ghost is None else int(ghost),
+                                        C.byref(ctx)))
+        self.ctx = ctx
+        p = make_params(params)
+        L.check(self.lib.fs_set_params(self.ctx, C.byref(p)), self.ctx)
+        info = (C.c_int * 6)()
+        L.check(self.lib.fs_slab_info(self.ctx, info))
+        self.r0, self.r1, self.b0, self.b1, self.G = info[0], info[1], info[2], info[3], info[4]
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.fs_destroy(self.ctx)
+            self.ctx = None
+
+    def add_force(self, pos, force, color, dt=None):
+        col = (C.c_float * 4)(float(color[0]), float(color[1]), float(color[2]), 0.0)
+        L.check(self.lib.fs_add_force(self.ctx, float(pos[0]), float(pos[1]), float(force[0]), float(force[1]), col,
+                                      self.radius, float(self.deltaTime if dt is None else dt)), self.ctx)
+
+    def sync(self):
+        L.check(self.lib.fs_sync(self.ctx), self.ctx)
+
+    def owned(self, name):
+        """The rows this slab owns of a field, [planes, r1-r0, W] on the host."""
+        fid = FIELDS[name]
+        out = np.empty((L.FIELD_PLANES[fid], self.r1 - self.r0, self.W), dtype=F)
+        L.check(self.lib.fs_read_field(self.ctx, fid, out.ctypes.data_as(C.c_void_p), out.nbytes), self.ctx)
+        return out
+
+    def write_owned(self, name, arr):
+        fid = FIELDS[name]
+        a = np.ascontiguousarray(arr, dtype=F)
+        assert a.shape == (L.FIELD_PLANES[fid], self.r1 - self.r0, self.W), a.shape
+        L.check(self.lib.fs_write_field(self.ctx, fid, a.ctypes.data_as(C.c_void_p), a.nbytes), self.ctx)
+
+    @property
+    def last_halo(self):
+        info = (C.c_int * 6)()
+        L.check(self.lib.fs_slab_info(self.ctx, info))
+        return info[5]
+
+    @property
+    def stats(self):
+        st = (C.c_long * 3)()
+        L.check(self.lib.fs_slab_stats(self.ctx, st))
+        return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2]}
+
+
+class RcclSlab(_Slab):
+    """One rank's slab of a multi-process run: halos over RCCL send/recv inside the library."""
+
+    def __init__(self, W, H, params, device, rank, world, dist=None, ghost=None):
+        lib = L.load()
+        ident = np.zeros(L.COMM_ID_BYTES, np.uint8)
+        if rank == 0:
+            L.check(lib.fs_comm_unique_id(ident.ctypes.data_as(C.c_void_p)))
+        if world > 1:
+            if dist is None:
+                raise ValueError("world > 1 needs an initialised torch.distributed group to hand out the RCCL id")
+            import torch
+            t = torch.from_numpy(ident)
+            if dist.get_backend() == "nccl":
+                t = t.cuda(device)
+            dist.broadcast(t, 0)
+            ident = t.cpu().numpy().copy()
+        comm = C.c_void_p()
+        L.check(lib.fs_comm_create_rccl(int(world), int(rank), int(device), ident.ctypes.data_as(C.c_void_p),
+                                        C.byref(comm)))
+        self.comm = comm
+        self.rank, self.world = rank, world
+        super().__init__(W, H, params, device, comm, rank, ghost)
+
+    def update(self):
+        L.check(self.lib.fs_step(self.ctx), self.ctx)
+
+    def frame(self, f, n_pointers=1, forceMultiplier=24.0, colorMultiplier=100.0):
+        """One scripted frame of SURVEY.md 8(d): one splat per virtual pointer (every rank applies every
+        splat to the rows it holds), then update()."""
+        for ptr in range(n_pointers):
+            pos, force, col = splat(self.W, self.H, f, ptr, n_pointers, forceMultiplier, colorMultiplier)
+            self.add_force(pos, force, col)
+        self.update()
+
+    def close(self):
+        super().close()
+        if getattr(self, "comm", None):
+            self.lib.fs_comm_destroy(self.comm)
+            self.comm = None
+
+
+class LocalGroup:
+    """K slabs of one W x H solver in this process, exchanging by device memcpy, stepped in lock step
+    (fs_group_step).  Exists to test the slab planner and kernels on a 1-GPU box."""
+
+    def __init__(self, W, H, params, world, device=0, ghost=None):
+        self.lib = L.load()
+        comm = C.c_void_p()
+        L.check(self.lib.fs_comm_create_local(int(world), C.byref(comm)))
+        self.comm = comm
+        self.world = world
+        self.W, self.H = int(W), int(H)
+        self.slabs = [_Slab(W, H, params, device, comm, r, ghost) for r in range(world)]
+        self._arr = (C.c_void_p * world)(*[s.ctx for s in self.slabs])
+
+    def add_force(self, pos, force, color, dt=None):
+        for s in self.slabs:
+            s.add_force(pos, force, color, dt)
+
+    def update(self):
+        rc = self.lib.fs_group_step(self._arr, self.world)
+        if rc:
+            raise L.FluidSolverError(rc, L.last_error(None) or L.last_error(self.slabs[0].ctx))
+
+    def sync(self):
+        for s in self.slabs:
+            s.sync()
+
+    def field(self, name):
+        """The whole field, stitched from the owned rows of every slab."""
+        return np.concatenate([s.owned(name) for s in self.slabs], axis=1)
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+        if self.comm:
+            self.lib.fs_comm_destroy(self.comm)
+            self.comm = None

@@ -257,6 +257,47 @@ int fs_default_particle_params(fs_particle_params *pp, float windowW, float wind
 int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
 long fs_particles_count(fs_ctx *ctx);
 
+/* -------------------------------------------------------------------------
+ * Layer 3: row slabs across GPUs.  No counterpart in the reference (one MTLDevice, Solver:269);
+ * the contract is SURVEY.md 8(e).  GPU g owns rows [g*H/k, (g+1)*H/k) and all columns; halo rows
+ * move with ncclSend/ncclRecv between slab neighbours over xGMI, two batched rounds per frame
+ * (deep ghost zones, recomputed redundantly), plus one 4-byte all-reduce(max) that sizes the
+ * advection halo from the CFL bound of the backtrace.  Every stage is the same kernel as on one
+ * GPU, so k slabs equal one GPU bit for bit.
+ *
+ * One process per GPU:
+ *     rank 0: fs_comm_unique_id(id); broadcast id to all ranks by any means (torch.distributed, MPI, a file)
+ *     all:    fs_comm_create_rccl(world, rank, device, id, &comm);
+ *             fs_create_slab(W, H, device, comm, rank, -1, &ctx);
+ *             per frame: fs_add_force(ctx, ...) with GLOBAL coordinates on EVERY rank; fs_step(ctx);
+ *     fs_read_field / fs_write_field move the rows the slab owns ([plane][r1-r0][W]).
+ * RCCL is loaded at run time (a librccl already in the process wins, else FS_RCCL_LIBRARY, else the
+ * default search path), so single-GPU hosts need none.
+ * ---------------------------------------------------------------------- */
+typedef struct fs_comm fs_comm;
+#define FS_COMM_ID_BYTES 128
+int fs_comm_unique_id(void *id128);   /* ncclGetUniqueId */
+int fs_comm_create_rccl(int world, int rank, int device, const void *id128, fs_comm **out);
+/* In-process group: all `world` slabs live in this process (on one GPU or several) and exchange by
+ * device memcpy.  It exists to test the slab logic on a 1-GPU box; step it with fs_group_step. */
+int fs_comm_create_local(int world, fs_comm **out);
+int fs_comm_destroy(fs_comm *comm);   /* after the contexts that use it */
+/* Round trip through an RCCL communicator (collective: every rank calls it): `count` floats to the
+ * next rank / from the previous one in one send/recv group, and a 1-float all-reduce(max). */
+int fs_comm_selftest(fs_comm *comm, int count);
+
+/* ghost_rows = capacity per interior side; < 0 picks one whole slab.  It bounds the advection halo
+ * (FS_ERR_HALO from fs_step when ceil(max|v_y| dt) + 2 exceeds it); values above the slab height
+ * are legal (rows then come from several ranks).  Tracers and fs_stage are single-GPU only. */
+int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out);
+int fs_slab_info(fs_ctx *ctx, int info[6]);   /* r0, r1 (owned rows), b0, b1 (buffered rows), ghost capacity, last advection halo */
+int fs_slab_stats(fs_ctx *ctx, long stats[3]); /* exchange rounds, halo rows sent, frames */
+int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
+/* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
+ * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f. */
+int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, const fs_params *p, int frames,
+                      const int *halos, char *buf, size_t cap);
+
 const char *fs_last_error(fs_ctx *ctx); /* ctx may be NULL: last error of the calling thread */
 const char *fs_version(void);
 

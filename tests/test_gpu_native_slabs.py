@@ -1,0 +1,164 @@
+"""Native row-slab path (layer 3 of include/fluidsolver.h: planner + kernels + transport inside the
+library) on the 1-GPU test box.  RCCL needs one GPU per rank, so K slabs run here as an in-process
+group (fs_comm_create_local / fs_group_step): same planner, same kernels, same exchange segments,
+device memcpy instead of ncclSend/ncclRecv.  The RCCL transport itself is exercised with a
+single-rank communicator (send/recv to self + all-reduce).  Every result must equal the unsplit
+run bit for bit (SURVEY.md 8(e) "Exactness")."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+F = np.float32
+
+CASES = {
+    # name: (W, H, params, ghost capacity, frames, force scale)
+    "config2_physics": (600, 500, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), None, 3, 0.02),
+    "thin_ghost_rechunks": (300, 260, (1.5e-4, 0.00001, 0.5, 10.0, 0.002, 20), 12, 3, 0.02),
+    "multi_hop_ghost": (200, 180, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 8), 180, 3, 6.0),
+    "dye_diffusion": (260, 240, (0.00005, 0.00001, 0.4, 10.0, 0.008, 5), None, 3, 0.05),
+    "no_viscosity_no_vorticity": (192, 161, (0.0, 0.0, 0.5, 0.0, 0.02, 4), None, 3, 0.05),
+}
+
+
+def _run_group(case, world):
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params, ghost, frames, fscale = case
+    g = LocalGroup(W, H, params, world, device=0, ghost=ghost)
+    try:
+        halos = []
+        for f in range(frames):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, 2)
+                g.add_force(pos, (force[0] * F(fscale), force[1] * F(fscale)), col)
+            g.update()
+            halos.append(g.slabs[0].last_halo)
+        g.sync()
+        return g.field("vel"), g.field("dye"), g.field("p"), halos, [s.stats for s in g.slabs]
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_local_group_equals_oracle(oracle_omp, world, name):
+    import test_slabs as T
+    case = CASES[name]
+    vel, dye, prs, halos, stats = _run_group(case, world)
+    rvel, rdye, rprs = T._reference(case)
+    assert np.array_equal(vel, rvel), (name, "vel")
+    assert np.array_equal(dye, rdye), (name, "dye")
+    assert np.array_equal(prs, rprs), (name, "p")
+    assert np.abs(rvel).max() > 0
+    if name == "multi_hop_ghost" and world == 5:
+        assert max(halos) > case[1] // world, "the case is meant to need rows from beyond the neighbour: %r" % halos
+    if name == "config2_physics":
+        # two exchange rounds per frame (one in the first frame, whose all-zero fields need none at its start)
+        assert all(s["exchanges"] == 2 * case[4] - 1 for s in stats), stats
+
+
+def test_local_group_equals_single_gpu_context_at_size():
+    """4 slabs of a 1536 x 1024 grid, N = 40, against fs_step on the whole grid (no oracle: too slow)."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params = 1536, 1024, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    g = LocalGroup(W, H, params, 4, device=0)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        for f in range(6):
+            for ptr in range(4):
+                pos, force, col = splat(W, H, 7 * f + 1, ptr, 4)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+        g.sync()
+        s.sync()
+        assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
+        assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
+        assert np.abs(g.field("vel")).max() > 0
+    finally:
+        g.close()
+        s.close()
+
+
+def test_written_fields_invalidate_ghosts():
+    """fs_write_field on a slab marks its ghost rows stale: the next frame must fetch them."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params, world = 320, 210, (1.5e-4, 0.0, 0.5, 5.0, 0.002, 9), 3
+    rng = np.random.default_rng(7)
+    vel = rng.uniform(-2, 2, (2, H, W)).astype(F)
+    dye = rng.uniform(0, 1, (3, H, W)).astype(F)
+    g = LocalGroup(W, H, params, world, device=0)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        for sl in g.slabs:
+            sl.write_owned("vel", vel[:, sl.r0:sl.r1])
+            sl.write_owned("dye", dye[:, sl.r0:sl.r1])
+        s.write_field(L.FIELD_VELOCITY, vel)
+        s.write_field(L.FIELD_DENSITY, dye)
+        for _ in range(2):
+            g.update()
+            s.update()
+        g.sync()
+        s.sync()
+        assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
+    finally:
+        g.close()
+        s.close()
+
+
+def test_halo_beyond_ghost_capacity_is_reported():
+    """A flow faster than the ghost capacity allows must fail loudly (FS_ERR_HALO), never silently."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params = 200, 180, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 8)
+    g = LocalGroup(W, H, params, 3, device=0, ghost=6)
+    try:
+        g.add_force((100.0, 90.0), (0.0, 4000.0), (1.0, 1.0, 1.0))
+        with pytest.raises(L.FluidSolverError) as e:
+            g.update()
+        assert e.value.code == -4 and "ghost capacity" in str(e.value)
+    finally:
+        g.close()
+
+
+def test_rccl_transport_single_rank():
+    """The RCCL transport on the box's one GPU: communicator of world 1, grouped send/recv to self and
+    the all-reduce (fs_comm_selftest), then a slab context on it stepping like a plain context."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import RcclSlab
+    from fluidsolver_amd.script import splat
+    W, H, params = 384, 256, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 12)
+    a = RcclSlab(W, H, params, device=0, rank=0, world=1)
+    b = FluidSolver(W, H)
+    (b.viscosity, b.diffusion, b.deltaTime, b.vorticityStrength, b.fadeSpeed, b.solverIterations) = params
+    b.displayMode = None
+    try:
+        L.check(a.lib.fs_comm_selftest(a.comm, 3 * 4096))
+        for f in range(3):
+            pos, force, col = splat(W, H, 3 * f + 1)
+            a.add_force(pos, force, col)
+            b.applyForce(pos, force, col)
+            a.update()
+            b.update()
+        a.sync()
+        b.sync()
+        assert np.array_equal(a.owned("vel"), b.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(a.owned("dye"), b.read_field(L.FIELD_DENSITY))
+    finally:
+        a.close()
+        b.close()

@@ -1,0 +1,133 @@
+"""The native frame planner (fluidsolver_amd/csrc/slab.hip, dumped by fs_slab_plan_dump -- host code,
+no GPU) against the Python planner (fluidsolver_amd/slabs.py), which the gloo tests of test_slabs.py
+prove bit-exact against the unsplit oracle.  Same stages, same row ranges, same exchange depths, in
+the same order, for every rank and over several frames (ghost depths carry over between frames)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from fluidsolver_amd import native_slabs as NS  # noqa: E402
+from fluidsolver_amd.slabs import SlabSolver  # noqa: E402
+
+
+class _Recorder:
+    """Backend that records what the Python planner launches instead of computing it."""
+
+    def __init__(self, log):
+        self.log = log
+        self.next_cfl = 0.0
+
+    def alloc(self, planes, rows, pitch, device):
+        return torch.zeros((planes, 1, 1))     # the planner never looks inside
+
+    def alloc_int(self, device):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def _rec(self, name, g, n=0):
+        self.log.append("%s %d %d %d" % (name, g.yb, g.ye, n))
+
+    def vorticity(self, g, vel, w): self._rec("vorticity", g)
+    def applyVorticity(self, g, w, vel, s, dt): self._rec("applyVorticity", g)
+    def divergence(self, g, vel, div): self._rec("divergence", g)
+    def clear(self, g, t): self._rec("clear", g)
+    def subtractGradient(self, g, p, vel): self._rec("subtractGradient", g)
+    def fade(self, g, dye, rate): self._rec("fade", g)
+    def advect(self, g, vel, src, dst, dt, err): self._rec("advect", g, src.shape[0])
+    def advect_fade(self, g, vel, src, dst, dt, rate, err): self._rec("advect_fade", g, src.shape[0])
+
+    def diffuse_n(self, g, a, b, n, visc, dt):
+        self._rec("diffuse_n", g, n)
+        return bool(self._launches(1, n) & 1)
+
+    def pressure_n(self, g, div, pa, pb, n, p_is_zero):
+        self._rec("pressure_n", g, n)
+        return bool(self._launches(0, n) & 1)
+
+    @staticmethod
+    def _launches(op, n):
+        from fluidsolver_amd import lib as L
+        depth = L.load().fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE if op else L.OPT_BLOCK_DEPTH_PRESSURE)
+        return (n + depth - 1) // depth
+
+    def max_abs(self, g, plane, out):
+        self._rec("max_abs", g)
+        out.fill_(self.next_cfl)
+
+
+class _Comm:
+    def __init__(self, rank, world, log):
+        self.rank, self.world, self.log = rank, world, log
+
+    def allreduce_max(self, t):
+        self.log.append("cfl_allreduce")
+
+
+class _PlanOnly(SlabSolver):
+    def _ensure(self, wants):
+        if self.world == 1:
+            return
+        todo = [(n, min(d, self.G)) for n, d in wants if self.valid[n] < min(d, self.G)]
+        if todo:
+            self.comm.log.append("exchange " + " ".join("%s:%d" % t for t in todo))
+            for n, d in todo:
+                self.valid[n] = d
+
+
+def python_plan(W, H, world, rank, ghost, params, halos):
+    log = []
+    be = _Recorder(log)
+    s = _PlanOnly(W, H, params, device="cpu", comm=_Comm(rank, world, log) if world > 1 else None, backend=be,
+                  ghost=ghost)
+    s.comm = _Comm(rank, world, log) if world > 1 else None
+    dt = abs(params[2])
+    for h in halos:
+        be.next_cfl = (h - 2.5) / dt if world > 1 else 0.0   # ceil(cfl * dt) + 2 == h
+        s.update()
+        if world > 1:
+            assert s.last_halo == h
+    return "\n".join(log) + "\n"
+
+
+CASES = {
+    # name: (W, H, params, ghost, halos per frame)
+    "config2_8gpu": (16384, 16384, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), None, [2, 9, 30]),
+    "config5_weak": (8192, 65536, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 100), None, [3, 3]),
+    "thin_ghost_rechunks": (300, 260, (1.5e-4, 0.00001, 0.5, 10.0, 0.002, 20), 12, [3, 5, 12]),
+    "tiny_ghost": (128, 96, (1.5e-4, 0.0, 0.25, 10.0, 0.002, 7), 2, [2, 2]),
+    "dye_diffusion": (70, 84, (0.00005, 0.00001, 0.5, 10.0, 0.008, 5), None, [4, 6, 2]),
+    "no_viscosity_no_vorticity": (64, 61, (0.0, 0.0, 0.5, 0.0, 0.02, 4), None, [3, 3]),
+    "zero_iterations": (64, 64, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 0), None, [2, 2]),
+    "uneven_rows": (100, 103, (1.5e-4, 0.0, 0.5, 0.0, 0.002, 11), 9, [4, 9]),
+}
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_native_plan_equals_python_plan(name, world):
+    W, H, params, ghost, halos = CASES[name]
+    if H // world < 4:
+        pytest.skip("slabs too thin")
+    for rank in sorted({0, world // 2, world - 1}):
+        native = NS.plan_dump(W, H, world, rank, ghost, params, halos)
+        python = python_plan(W, H, world, rank, ghost, params, halos)
+        assert native == python, "rank %d of %d\n--- native ---\n%s--- python ---\n%s" % (rank, world, native, python)
+        assert "subtractGradient" in native
+        if world > 1:
+            assert "cfl_allreduce" in native
+
+
+def test_deep_halo_plan_has_two_exchange_rounds_per_frame():
+    """Config 4 on 8 GPUs: after the first frame (all-zero fields need no exchange) every frame costs
+    exactly two exchange rounds -- velocity at frame start, velocity + dye before advection."""
+    W, H, params, ghost, _ = CASES["config2_8gpu"]
+    text = NS.plan_dump(W, H, 8, 3, None, params, [5, 5, 5])
+    frames = text.split("cfl_allreduce\n")
+    assert len(frames) == 4
+    assert text.count("exchange") == 1 + 2 + 2      # frame 0: only the pre-advection round
+    assert "exchange vel:83\n" in text              # 2N + 3 rows of velocity in one round
+    assert "exchange vel:5 dye:5\n" in text
