@@ -5,8 +5,8 @@
 
 A "step" is one frame: one scripted splat + FluidSolver.update() (+ the tracer
 update for config3).  N = 1 runs the workload on one GPU through the solver context (hipGraph);
-N > 1 (launched by torch.distributed.run, one rank per GPU) runs row slabs with halo exchange over
-RCCL.  Rank 0 prints ONE JSON line.
+N > 1 (launched by torch.distributed.run, one rank per GPU) runs row slabs through the library's
+native slab runtime: halo rows by ncclSend/ncclRecv over xGMI.  Rank 0 prints ONE JSON line.
 
 value = cells x frames/s / 1e9 (Gcell-updates/s of whole frames), inputs resident in HBM.
 roofline = the pressure Jacobi kernel (k_jacobi_block<pressure>), effective bandwidth =
@@ -36,7 +36,7 @@ WORKLOADS = {
                     desc="3072x3072 full step: vorticity + diffuse + 40 pressure iters + RGB dye advect"),
     "config3": dict(W=3072, H=3072, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=1 << 20, scaling="weak",
                     desc="config2 + 1,048,576 tracer particles"),
-    "config4": dict(W=16384, H=16384, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=0, scaling="strong",
+    "config4": dict(W=16384, H=16384, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), particles=0, scaling="strong", pointers=8,
                     desc="16384x16384 full step, row slabs, strong scaling"),
     "config5": dict(W=8192, H=8192, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 100), particles=0, scaling="weak",
                     desc="8192x8192 per GPU, 100 pressure iters, weak scaling"),
@@ -65,10 +65,11 @@ def make_single(W, H, params, particles):
     return s, ps
 
 
-def frame_single(s, ps, f, W, H):
+def frame_single(s, ps, f, W, H, n_pointers=1):
     from fluidsolver_amd.script import splat
-    pos, force, col = splat(W, H, f)
-    s.applyForce(pos, force, col)
+    for ptr in range(n_pointers):
+        pos, force, col = splat(W, H, f, ptr, n_pointers)
+        s.applyForce(pos, force, col)
     s.update()
     if ps is not None:
         ps.update(s, (W, H))
@@ -150,8 +151,6 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    if os.environ.get("FS_BENCH_REHEARSAL") == "1":
-        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from fluidsolver_amd import lib as L
@@ -165,32 +164,27 @@ def main():
     if world == 1:
         H = Hg
         s, ps = make_single(W, H, params, wl["particles"])
-        step = lambda f: frame_single(s, ps, f, W, H)   # noqa: E731
+        n_ptr = wl.get("pointers", 1)
+        step = lambda f: frame_single(s, ps, f, W, H, n_ptr)   # noqa: E731
         barrier = lambda: None                          # noqa: E731
         sync_all = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
         total_cells = W * H
         parallelism = "1 GPU"
     else:
         import torch.distributed as dist
-        from fluidsolver_amd.slabs import SlabSolver
-        # FS_BENCH_REHEARSAL=1: rehearse the multi-rank code path on a 1-GPU box (all ranks on cuda:0,
-        # halos staged through the host over gloo).  Never set by the driver; numbers are meaningless.
-        rehearsal = os.environ.get("FS_BENCH_REHEARSAL") == "1"
-        if rehearsal:
-            from fluidsolver_amd.slabs import Comm
-            dist.init_process_group("gloo")
-            comm = Comm(stage_through_host=True)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            comm = None
+        from fluidsolver_amd.native_slabs import RcclSlab
+        # Control plane (RCCL unique id, barriers, max of the timings): torch.distributed over gloo.
+        # Data plane (halo rows, CFL all-reduce): ncclSend/ncclRecv/ncclAllReduce inside the library.
+        dist.init_process_group("gloo")
         H = Hg * world if wl["scaling"] == "weak" else Hg
-        s = SlabSolver(W, H, params, device=local_rank, comm=comm)
-        n_ptr = world
+        s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
+        L.check(lib.fs_comm_selftest(s.comm, 1 << 16))
+        n_ptr = wl.get("pointers", world)   # weak scaling: one pointer per slab; config 4: always eight
         step = lambda f: s.frame(f, n_pointers=n_ptr)   # noqa: E731
         barrier = dist.barrier
         sync_all = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
         total_cells = W * H
-        parallelism = "%d row slabs (RCCL halo exchange)" % world
+        parallelism = "%d row slabs (RCCL send/recv halo exchange over xGMI)" % world
 
     for f in range(args.warmup):
         step(f)
@@ -205,7 +199,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -249,9 +243,10 @@ def main():
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
     if world > 1:
-        out["slab"] = {"ghost_rows": s.G, "last_advect_halo": getattr(s, "last_halo", None),
-                       "exchange_rounds_per_frame": s.stats["exchanges"] / float(args.warmup + args.steps),
-                       "gathers": s.stats["gathers"]}
+        st = s.stats
+        out["slab"] = {"rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+                       "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
+                       "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"]))}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -44,7 +44,7 @@ def _run_group(case, world):
         g.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_local_group_equals_oracle(oracle_omp, world, name):
     import test_slabs as T
@@ -55,9 +55,9 @@ def test_local_group_equals_oracle(oracle_omp, world, name):
     assert np.array_equal(dye, rdye), (name, "dye")
     assert np.array_equal(prs, rprs), (name, "p")
     assert np.abs(rvel).max() > 0
-    if name == "multi_hop_ghost" and world == 5:
+    if name == "multi_hop_ghost" and world == 8:
         assert max(halos) > case[1] // world, "the case is meant to need rows from beyond the neighbour: %r" % halos
-    if name == "config2_physics":
+    if name == "config2_physics" and world <= 3:
         # two exchange rounds per frame (one in the first frame, whose all-zero fields need none at its start)
         assert all(s["exchanges"] == 2 * case[4] - 1 for s in stats), stats
 
