@@ -14,6 +14,8 @@ int config_set_block_depth(int op, int v);
 int config_get_block_depth(int op);
 int config_set_tile_variant(int v);
 int config_get_tile_variant();
+int config_set_stagger(int ticks, int mode);
+int config_get_stagger();
 
 static thread_local char tl_error[512] = "";
 
@@ -576,6 +578,8 @@ int fs_config_set(int key, int value)
     if (key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_set_block_depth(0, value);
     if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_set_block_depth(1, value);
     if (key == FS_OPT_TILE_VARIANT) return fs::config_set_tile_variant(value);
+    if (key == FS_OPT_STAGGER) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(value, -1);
+    if (key == FS_OPT_STAGGER_MODE) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(-1, value);
     return FS_ERR_INVALID;
 }
 int fs_config_get(int key)
@@ -583,6 +587,7 @@ int fs_config_get(int key)
     if (key == FS_OPT_BLOCK_DEPTH || key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_get_block_depth(0);
     if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_get_block_depth(1);
     if (key == FS_OPT_TILE_VARIANT) return fs::config_get_tile_variant();
+    if (key == FS_OPT_STAGGER) return fs::config_get_stagger();
     return FS_ERR_INVALID;
 }
 

@@ -39,6 +39,8 @@ struct JacobiArgs {
     int HX;            // horizontal halo, multiple of 4, >= T
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
+    int stagger;       // start delay of every other resident workgroup, 10 ns ticks (0 = off)
+    int stagger_mode;
 };
 
 // x / den for a launch-constant den, bit-identical to the IEEE fp32 division the reference formula
@@ -52,20 +54,60 @@ struct JacobiArgs {
 // of den by fs_selftest_divide (tests/test_gpu_kernels.py).
 __device__ __forceinline__ float div_const(float x, double rden) { return (float)((double)x * rden); }
 
+// A lane's 4 cells of one row as two register pairs, so that every add/mul below that has no
+// cross-lane operand is ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32: two IEEE fp32 results
+// per lane per issue; same rounding as the scalar forms).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Row {
+    v2f a, b;   // a = columns (4l, 4l+1), b = columns (4l+2, 4l+3)
+};
+__device__ __forceinline__ Row row_of(float4 v) { return Row{v2f{v.x, v.y}, v2f{v.z, v.w}}; }
+__device__ __forceinline__ float4 f4_of(const Row &r) { return make_float4(r.a.x, r.a.y, r.b.x, r.b.y); }
+
+// Keeps a scalar sum scalar: without it the compiler re-packs the two adds that take a DPP operand
+// (v_add_f32_dpp: the neighbour lane's value folded into the add) into a v_pk_add_f32 whose operand
+// pair it first has to assemble with two extra moves.
+#define FS_SCALAR(x) asm("" : "+v"(x))
+
+// One sweep of the lane's 4 cells of a row.  c = this row, up/dn = the rows above/below (previous
+// iterate), d = divergence (pressure only).  Evaluation order is the reference's:
+//   pressure  ((((div + l) + r) + t) + b) / 4                      Shaders:212 (x/4 == x*0.25 exactly)
+//   diffuse   (c + a * (((l + r) + t) + b)) / (1 + 4a)             Shaders:103
+// 13 VALU instructions per 4 cells for pressure (the scalar form took 20 + moves).
 template <int OP>
-__device__ __forceinline__ float sweep_cell(float c, float l, float r, float t, float b, float d, float a, double rden)
+__device__ __forceinline__ Row sweep_row(const Row &c, const Row &up, const Row &dn, const Row &d, float a, double rden)
 {
+    const float lx = from_lane_below(c.b.y);   // column 4l-1
+    const float rw = from_lane_above(c.a.x);   // column 4l+4
+    Row n;
     if (OP == OP_PRESSURE) {
-        return ((((d + l) + r) + t) + b) / 4.0f;                  // Shaders:212 (x/4 == x*0.25 exactly)
+        const v2f mid = {c.a.y, c.b.x};        // right neighbours of pair a == left neighbours of pair b
+        float t0 = d.a.x + lx, t1 = d.a.y + c.a.x;
+        FS_SCALAR(t0); FS_SCALAR(t1);
+        const v2f sa = v2f{t0, t1} + mid;
+        const v2f sb0 = d.b + mid;
+        float t2 = sb0.x + c.b.y, t3 = sb0.y + rw;
+        FS_SCALAR(t2); FS_SCALAR(t3);
+        const v2f sb = {t2, t3};
+        const v2f quarter = {0.25f, 0.25f};
+        n.a = ((sa + up.a) + dn.a) * quarter;
+        n.b = ((sb + up.b) + dn.b) * quarter;
     } else {
-        return div_const(c + a * (((l + r) + t) + b), rden);      // Shaders:103
+        float t0 = lx + c.a.y, t1 = c.a.x + c.b.x, t2 = c.a.y + c.b.y, t3 = c.b.x + rw;
+        FS_SCALAR(t0); FS_SCALAR(t1); FS_SCALAR(t2); FS_SCALAR(t3);
+        const v2f av = {a, a};
+        const v2f xa = c.a + av * ((v2f{t0, t1} + up.a) + dn.a);
+        const v2f xb = c.b + av * ((v2f{t2, t3} + up.b) + dn.b);
+        n.a = v2f{div_const(xa.x, rden), div_const(xa.y, rden)};
+        n.b = v2f{div_const(xb.x, rden), div_const(xb.y, rden)};
     }
+    return n;
 }
 
 // T sweeps on the register tile.  EDGE = the tile touches a fixed (boundary / outside) row or column;
 // interior tiles (the vast majority) run the lean instantiation with no selects at all.
 template <int OP, int R, int NW, bool EDGE>
-__device__ __forceinline__ void run_sweeps_tile(float4 (&p)[R], const float4 (&d)[R], float4 (*xch)[NW][2][64], int T,
+__device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], float4 (*xch)[NW][2][64], int T,
                                                 int lane, int wave, unsigned rowfixed, bool fx0, bool fx1, bool fx2,
                                                 bool fx3, float a, double rden)
 {
@@ -73,29 +115,23 @@ __device__ __forceinline__ void run_sweeps_tile(float4 (&p)[R], const float4 (&d
     const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
     for (int s = 0; s < T; ++s) {
         const int buf = s & 1;
-        xch[buf][wave][0][lane] = p[0];
-        xch[buf][wave][1][lane] = p[R - 1];
+        xch[buf][wave][0][lane] = f4_of(p[0]);
+        xch[buf][wave][1][lane] = f4_of(p[R - 1]);
         __syncthreads();
-        float4 prev = xch[buf][wup][1][lane];           // row above this wave's strip
-        const float4 below = xch[buf][wdn][0][lane];    // row below it
+        Row prev = row_of(xch[buf][wup][1][lane]);           // row above this wave's strip
+        const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const float4 c = p[i];
-            const float4 nx = (i < R - 1) ? p[i + 1] : below;
-            const float l = from_lane_below(c.w);   // column 4l-1
-            const float r = from_lane_above(c.x);   // column 4l+4
-            float4 n;
-            n.x = sweep_cell<OP>(c.x, l, c.y, prev.x, nx.x, d[i].x, a, rden);
-            n.y = sweep_cell<OP>(c.y, c.x, c.z, prev.y, nx.y, d[i].y, a, rden);
-            n.z = sweep_cell<OP>(c.z, c.y, c.w, prev.z, nx.z, d[i].z, a, rden);
-            n.w = sweep_cell<OP>(c.w, c.z, r, prev.w, nx.w, d[i].w, a, rden);
+            const Row c = p[i];
+            const Row nx = (i < R - 1) ? p[i + 1] : below;
+            Row n = sweep_row<OP>(c, prev, nx, d[i], a, rden);
             if (EDGE) {
                 // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
-                const float4 fixedv = OP == OP_PRESSURE ? make_float4(0.f, 0.f, 0.f, 0.f) : c;
-                if (fx0) n.x = fixedv.x;
-                if (fx1) n.y = fixedv.y;
-                if (fx2) n.z = fixedv.z;
-                if (fx3) n.w = fixedv.w;
+                const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
+                if (fx0) n.a.x = fixedv.a.x;
+                if (fx1) n.a.y = fixedv.a.y;
+                if (fx2) n.b.x = fixedv.b.x;
+                if (fx3) n.b.y = fixedv.b.y;
                 if ((rowfixed >> i) & 1u) n = fixedv;
             }
             p[i] = n;
@@ -116,6 +152,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     const GK g = A.g;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // De-phase the workgroups that share a CU.  All workgroups of the first dispatch wave start together
+    // and would all load, then all sweep, then all store: HBM idles while the VALUs run and vice versa.
+    // Holding back every other resident workgroup by about one load phase lets one workgroup of a CU
+    // stream its tile while the other sweeps.  Timing only: results do not depend on it.
+    if (A.stagger > 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        bool late;
+        switch (A.stagger_mode & 15) {
+        case 1: late = (lin & 1u) != 0 && lin < 512u; break;
+        case 2: late = ((lin >> 3) & 1u) != 0 && lin < 512u; break;
+        case 3: late = ((lin >> 8) & 1u) != 0; break;
+        default: late = ((lin >> 8) & 1u) != 0 && lin < 512u; break;
+        }
+        if (late) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < A.stagger) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const int OW = TW - 2 * A.HX;
     const int OH = TH - 2 * A.T;
     const int x0 = blockIdx.x * OW - A.HX;               // tile column 0 (global), multiple of 4
@@ -135,8 +189,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     // block-uniform: does this tile touch a fixed column or row at all?
     const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1 || ry0 <= 0 || ry0 + TH >= g.H - 1;
 
-    float4 p[R];
-    float4 d[R];
+    Row p[R];
+    Row d[R];
     unsigned rowfixed = 0;  // bit i: row i is a boundary row or outside the domain (wave-uniform)
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -146,19 +200,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         rowfixed |= (rf ? 1u : 0u) << i;
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row_in_buf && col_in_buf) {
+        if (row_in_buf && col_in_buf && !(A.stagger_mode & 32)) {
             const size_t o = row_off(g, y) + gx;
             if (in) pv = ld4(in + o);
             if (OP == OP_PRESSURE) dv = ld4(A.div + o);
         }
-        p[i] = pv;
-        d[i] = dv;
+        p[i] = row_of(pv);
+        d[i] = row_of(dv);
     }
 
+    const int Trun = (A.stagger_mode & 16) ? 0 : A.T;
     if (edge_tile)
-        run_sweeps_tile<OP, R, NW, true>(p, d, xch, A.T, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
+        run_sweeps_tile<OP, R, NW, true>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
     else
-        run_sweeps_tile<OP, R, NW, false>(p, d, xch, A.T, lane, wave, 0u, false, false, false, false, A.a, A.rden);
+        run_sweeps_tile<OP, R, NW, false>(p, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
 
     // store the exact inner region
     const bool col_out = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
@@ -167,7 +222,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         for (int i = 0; i < R; ++i) {
             const int ty = wave * R + i;
             const int y = wy0 + i;
-            if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + gx, p[i]);
+            if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + gx, f4_of(p[i]));
         }
     }
 }
@@ -177,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 // fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
 static int g_block_depth[2] = {10, 8};   // [OP_PRESSURE], [OP_DIFFUSE]
 static int g_tile_variant = 0;   // index into the (R rows per lane, NW waves) table below
+static int g_stagger = 0, g_stagger_mode = 0;
 
 template <int OP, int R, int NW, int MINW>
 static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, hipStream_t stream)
@@ -207,6 +263,8 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.a = a;
     A.den = den;
     A.rden = 1.0 / (double)den;
+    A.stagger = g_stagger;
+    A.stagger_mode = g_stagger_mode;
     switch (g_tile_variant) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
@@ -273,6 +331,13 @@ int config_set_tile_variant(int v)
     return FS_OK;
 }
 int config_get_tile_variant() { return g_tile_variant; }
+int config_set_stagger(int ticks, int mode)
+{
+    if (ticks >= 0) g_stagger = ticks;
+    if (mode >= 0) g_stagger_mode = mode;
+    return FS_OK;
+}
+int config_get_stagger() { return g_stagger; }
 
 // exhaustive check of div_const against the IEEE division: all 2^32 bit patterns of x
 __global__ __launch_bounds__(256) void k_selftest_divide(float den, double rden, unsigned long long *mismatches)

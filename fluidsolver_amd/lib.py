@@ -18,7 +18,7 @@ FIELD_PLANES = {FIELD_VELOCITY: 2, FIELD_DENSITY: 3, FIELD_PRESSURE: 1, FIELD_DI
                 FIELD_VORTICITY: 1, FIELD_DISPLAY: 4}
 DISPLAY_NONE, DISPLAY_DENSITY, DISPLAY_VELOCITY, DISPLAY_SPEED, DISPLAY_VORTICITY, DISPLAY_PARTICLES_ONLY = -1, 0, 1, 2, 3, 4
 OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES, OPT_TILE_VARIANT, OPT_FUSE = 0, 1, 2, 3, 4
-OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE = 5, 6
+OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE = 5, 6, 7, 8
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
  STAGE_FADE, STAGE_RENDER) = range(12)
