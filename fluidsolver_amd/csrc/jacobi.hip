@@ -228,10 +228,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 }
 
 // tuning knobs (process-wide; see fs_config_set)
-// Depths from the 3072^2 sweep in profiles/r01_tune_jacobi.log: the pressure sweep is cheap per cell, so
+// From the 3072^2 sweeps in profiles/r01_tune_jacobi*.log.  Depths: the pressure sweep is cheap per cell, so
 // fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
+// Tile: 4 rows per lane x 16 waves (64 VGPRs, 8 waves per SIMD).  The sweeps are bound by VALU issue and by
+// the per-sweep barrier, and twice the waves hide both better than the larger register tiles do.
 static int g_block_depth[2] = {10, 8};   // [OP_PRESSURE], [OP_DIFFUSE]
-static int g_tile_variant = 0;   // index into the (R rows per lane, NW waves) table below
+static int g_tile_variant = 4;   // index into the (R rows per lane, NW waves) table below
 static int g_stagger = 0, g_stagger_mode = 0;
 
 template <int OP, int R, int NW, int MINW>
@@ -269,9 +271,9 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
     case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
-    case 4: return launch_variant<OP, 4, 16, 8>(A, g, nplanes, stream);   // 256 x 64 tile, 1024 threads
+    case 0: return launch_variant<OP, 8, 8, 4>(A, g, nplanes, stream);    // 256 x 64 tile, 512 threads
     case 5: return launch_variant<OP, 12, 8, 3>(A, g, nplanes, stream);   // 256 x 96 tile, 512 threads
-    default: return launch_variant<OP, 8, 8, 4>(A, g, nplanes, stream);   // 256 x 64 tile, 512 threads
+    default: return launch_variant<OP, 4, 16, 8>(A, g, nplanes, stream);  // 256 x 64 tile, 1024 threads
     }
 }
 

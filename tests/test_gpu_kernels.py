@@ -228,6 +228,45 @@ def test_block_depth_does_not_change_bits(lib, oracle, depth):
         lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("depth", [1, 5, 10])
+def test_every_tile_variant_matches_the_oracle(lib, oracle, variant, depth):
+    # every register-tile shape (rows per lane x waves) of the blocked kernel, both loops, edge and interior tiles
+    from fluidsolver_amd import lib as L
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    W, H, n = 700, 330, 13
+    div = rnd((H, W), 21, -1, 1)
+    vel = rnd((2, H, W), 22, -2, 2)
+    og = full_grid(W, H)
+    a, b = np.zeros((H, W), F), np.zeros((H, W), F)
+    va, vb = vel.copy(), np.zeros_like(vel)
+    for _ in range(n):
+        oracle.pressureSolve(og, div, a, b)
+        a, b = b, a
+        for pl in range(2):
+            oracle.diffuse(og, va[pl], vb[pl], 1.5e-4, 0.5)
+        va, vb = vb, va
+    old = (lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE), lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE),
+           lib.fs_config_get(L.OPT_TILE_VARIANT))
+    try:
+        ok(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
+        ok(lib.fs_config_set(L.OPT_TILE_VARIANT, variant))
+        g = grid(W, H)
+        dd, pa, pb = dev_planes(div), dev_planes(np.zeros((H, W), F)), dev_planes(np.zeros((H, W), F))
+        in_b = C.c_int(-1)
+        ok(lib.fs_k_pressureSolve_n(C.byref(g), ptr(dd), ptr(pa), ptr(pb), n, 1, C.byref(in_b), stream()))
+        sync()
+        assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
+        da, db = dev_planes(vel), dev_planes(np.zeros_like(vel))
+        ok(lib.fs_k_diffuse_n(C.byref(g), ptr(da), ptr(db), 2, da.stride(0), 1.5e-4, 0.5, n, C.byref(in_b), stream()))
+        sync()
+        assert np.array_equal(host_planes(db if in_b.value else da, W), va)
+    finally:
+        lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
+        lib.fs_config_set(L.OPT_TILE_VARIANT, old[2])
+
+
 @pytest.mark.parametrize("W,H", SIZES + [(600, 150)])
 @pytest.mark.parametrize("n", [1, 5, 8, 17])
 def test_diffuse_sweeps(lib, oracle, W, H, n):
