@@ -222,53 +222,82 @@ __global__ __launch_bounds__(256) void k_render_velocity(GK g, int yb, int ye, c
 }
 
 // ---------------------------------------------------------------------------
-// advect, Shaders:118-151.  One thread per cell: the velocity read and the output
-// write are coalesced dwords; the 4 bilinear taps per plane are a data-dependent
-// gather served by L1/L2 (neighbouring lanes trace to neighbouring cells).
+// advect, Shaders:118-151.  One thread per 4 cells of a row: the velocity read and the
+// output write are coalesced 16-byte accesses; the bilinear taps are a data-dependent
+// gather served by L1/L2 (neighbouring cells trace to neighbouring taps), two 8-byte
+// loads per cell and plane.
 // ---------------------------------------------------------------------------
 // FADE fuses the fadeDensity pass that follows the dye advection in update() (Solver:577-591): the value
 // a cell would be given by advect is passed through max(x*(1-fade), 0) before the one store, which is
 // exactly what the separate in-place kernel computes from the stored value (Shaders:331-332).
+// the two taps (x, x+1) of one row in one 8-byte load; the address is only 4-byte aligned, which global
+// loads accept (halves the number of gather instructions the texture-address unit has to expand)
+struct __attribute__((packed, aligned(4))) TapPair {
+    float a, b;
+};
+__device__ __forceinline__ TapPair ld_pair(const float *p) { return *reinterpret_cast<const TapPair *>(p); }
+
 template <int NP, bool FADE>
 __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const float *__restrict__ u,
                                                 const float *__restrict__ v, const float *in,
                                                 float *__restrict__ out, size_t stride, float dt, int *err,
                                                 float fade_k)
 {
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = yb + blockIdx.y * 4 + threadIdx.y;
-    if (x >= g.W || y >= ye) return;
-    size_t o = row_off(g, y) + x;
-    if (is_boundary(g, x, y)) {                               // :127-130
+    const Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    const size_t o = row_off(g, q.y) + q.x;
+    const float4 uu = ld4(u + o), vv = ld4(v + o);
+    const float ux[4] = {uu.x, uu.y, uu.z, uu.w}, vy[4] = {vv.x, vv.y, vv.z, vv.w};
+    const bool rowb = q.y == 0 || q.y >= g.H - 1;
+    bool bnd[4], any_bnd = false, short_halo = false;
+    size_t o0[4], o1[4];
+    float sx[4], sy[4];
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            float x = in[c * stride + o];
-            out[c * stride + o] = FADE ? fmaxf(x * fade_k, 0.0f) : x;
+    for (int j = 0; j < 4; ++j) {
+        const int x = q.x + j;
+        bnd[j] = rowb || x == 0 || x >= g.W - 1;                  // :127-130 (padding columns count as boundary)
+        any_bnd |= bnd[j];
+        float posx = (float)x - ux[j] * dt;                       // :132-133
+        float posy = (float)q.y - vy[j] * dt;
+        posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
+        posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
+        const int i0x = (int)floorf(posx);                        // :140
+        int i0y = (int)floorf(posy);
+        sx[j] = posx - (float)i0x;                                // :142
+        sy[j] = posy - (float)i0y;
+        int i1y = i0y + 1;
+        if (i0y < g.y0 || i1y >= g.y0 + g.rows) {                 // slab halo too small: flag, stay in bounds
+            short_halo |= !bnd[j];
+            i0y = clamp_row(g, i0y);
+            i1y = clamp_row(g, i1y);
         }
-        return;
+        o0[j] = row_off(g, i0y) + i0x;
+        o1[j] = row_off(g, i1y) + i0x;
     }
-    float posx = (float)x - u[o] * dt;                        // :132-133
-    float posy = (float)y - v[o] * dt;
-    posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
-    posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
-    int i0x = (int)floorf(posx), i0y = (int)floorf(posy);     // :140
-    float sx = posx - (float)i0x, sy = posy - (float)i0y;     // :142
-    int i1y = i0y + 1;
-    if (i0y < g.y0 || i1y >= g.y0 + g.rows) {                 // slab halo too small: flag, stay in bounds
-        if (err) atomicOr(err, 1);
-        i0y = clamp_row(g, i0y);
-        i1y = clamp_row(g, i1y);
-    }
-    size_t o0 = row_off(g, i0y) + i0x, o1 = row_off(g, i1y) + i0x;
+    if (short_halo && err) atomicOr(err, 1);
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
         const float *p = in + c * stride;
-        float q00 = p[o0], q10 = p[o0 + 1];                   // :144-147
-        float q01 = p[o1], q11 = p[o1 + 1];
-        float m0 = q00 + (q10 - q00) * sx;                    // :149 mix(mix(),mix(),s.y)
-        float m1 = q01 + (q11 - q01) * sx;
-        float x = m0 + (m1 - m0) * sy;
-        out[c * stride + o] = FADE ? fmaxf(x * fade_k, 0.0f) : x;
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const TapPair r0 = ld_pair(p + o0[j]), r1 = ld_pair(p + o1[j]);   // :144-147
+            const float m0 = r0.a + (r0.b - r0.a) * sx[j];        // :149 mix(mix(),mix(),s.y)
+            const float m1 = r1.a + (r1.b - r1.a) * sx[j];
+            r[j] = m0 + (m1 - m0) * sy[j];
+        }
+        if (any_bnd) {                                            // boundary cells copy the input, :127-130
+            const float4 cen = ld4(p + o);
+            if (bnd[0]) r[0] = cen.x;
+            if (bnd[1]) r[1] = cen.y;
+            if (bnd[2]) r[2] = cen.z;
+            if (bnd[3]) r[3] = cen.w;
+        }
+        if (FADE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j] * fade_k, 0.0f);
+        }
+        st4(out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
@@ -488,7 +517,7 @@ static int launch_advect(const fs_grid *g, const float *u, const float *v, const
     REQUIRE(nplanes >= 1 && nplanes <= 3, "nplanes must be 1..3");
     REQUIRE(in != out, "advect cannot run in place");
     EMPTY_OK(g);
-    dim3 grid((g->width + 63) / 64, (g->ye - g->yb + 3) / 4, 1);
+    dim3 grid = quad_grid(g, 1);
     GK gk = make_gk(g);
     const float k = 1.0f - fadeRate;  // Shaders:331
 #define ADV(NP, FD) hipLaunchKernelGGL((k_advect<NP, FD>), grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag, k)
