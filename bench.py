@@ -75,9 +75,10 @@ def frame_single(s, ps, f, W, H, n_pointers=1):
         ps.update(s, (W, H))
 
 
-def jacobi_microbench(s, W, H, sweeps=40, reps=10):
-    """SURVEY 8(d) Jacobi micro-benchmark: pressureSolve alone on div ~ U(-1,1) (xorshift32 seed 1234),
-    HIP-event timed on the context's stream.  Returns (ms per launch, sweeps per launch, ms per sweep)."""
+def jacobi_microbench(s, W, H, sweeps=40, reps=25):
+    """SURVEY 8(d) Jacobi micro-benchmark: the pressure loop alone, exactly as update() runs it (p = 0 folded
+    into the first launch, Solver:528-541), on div ~ U(-1,1) (xorshift32 seed 1234), HIP-event timed on the
+    context's stream.  Returns (ms per launch, sweeps per launch, ms per sweep)."""
     from fluidsolver_amd import lib as L
     lib = L.load()
     div = np.empty((1, H, W), np.float32)
@@ -85,12 +86,12 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=10):
     s.write_field(L.FIELD_DIVERGENCE, div)
     s.write_field(L.FIELD_PRESSURE, np.zeros((1, H, W), np.float32))
     depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE)
-    s.stage(L.STAGE_PRESSURE, sweeps)   # warm-up
+    s.stage(L.STAGE_PRESSURE_CLEARED, sweeps)   # warm-up
     s.sync()
     ms = C.c_float()
     L.check(lib.fs_timer_begin(s.ctx), s.ctx)
     for _ in range(reps):
-        L.check(lib.fs_stage(s.ctx, L.STAGE_PRESSURE, sweeps), s.ctx)
+        L.check(lib.fs_stage(s.ctx, L.STAGE_PRESSURE_CLEARED, sweeps), s.ctx)
     L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
     launches = reps * ((sweeps + depth - 1) // depth)
     return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
@@ -121,8 +122,11 @@ def cpu_baseline(W, H, params, budget_s=20.0):
                 frames_per_s=fps, host_cpus=os.cpu_count())
 
 
-def load_traffic():
-    """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/), if any."""
+def load_traffic(workload):
+    """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/traffic.json,
+    collected on config 2 by scripts/profile_round.sh); null for any other workload."""
+    if workload != "config2":
+        return None
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -236,7 +240,7 @@ def main():
                          "sweeps_per_launch": sweeps_per_launch}
         out["roofline"] = {"kernel": "k_jacobi_block<pressure> (%g sweeps/launch)" % sweeps_per_launch,
                            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                            "note": "achieved = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
                                    "HIP-event launch time; temporal blocking keeps T sweeps on chip, so the "
                                    "effective figure may exceed the HBM peak"}

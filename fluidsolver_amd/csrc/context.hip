@@ -512,6 +512,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
     case FS_STAGE_ADVECT_DENSITY: rc = st_advect(c, F_DYE); break;
     case FS_STAGE_FADE: rc = fs_k_fadeDensity(&c->grid, c->f[F_DYE].p(), 3, c->plane, c->params.fadeSpeed, c->stream); break;   // :587-591
     case FS_STAGE_RENDER: rc = st_render(c); break;
+    case FS_STAGE_PRESSURE_CLEARED: rc = st_sweeps(c, F_P, n, true, true); break;                                  // :528-541
     default: fs::set_error("unknown stage %d", stage); rc = FS_ERR_INVALID;
     }
     return rc ? ctx_fail(c, rc) : FS_OK;

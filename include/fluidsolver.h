@@ -248,7 +248,8 @@ int fs_timer_end(fs_ctx *ctx, float *ms);
 /* run one stage of update() on the context's own fields (n = sweeps for the two loops) */
 enum { FS_STAGE_VORTICITY = 0, FS_STAGE_APPLY_VORTICITY, FS_STAGE_DIFFUSE_VELOCITY, FS_STAGE_DIVERGENCE,
        FS_STAGE_CLEAR_PRESSURE, FS_STAGE_PRESSURE, FS_STAGE_SUBTRACT_GRADIENT, FS_STAGE_ADVECT_VELOCITY,
-       FS_STAGE_DIFFUSE_DENSITY, FS_STAGE_ADVECT_DENSITY, FS_STAGE_FADE, FS_STAGE_RENDER };
+       FS_STAGE_DIFFUSE_DENSITY, FS_STAGE_ADVECT_DENSITY, FS_STAGE_FADE, FS_STAGE_RENDER,
+       FS_STAGE_PRESSURE_CLEARED /* clearTexture + the n sweeps exactly as update() runs them (clear folded in) */ };
 int fs_stage(fs_ctx *ctx, int stage, int n);
 
 /* Tracers (SoA on the device, owned by the context). */
