@@ -37,3 +37,13 @@ for f in range(50):
     s.update()
 L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
 print("update() graph     %8.1f us" % (ms.value * 1e3 / 50))
+s.set_option(L.OPT_USE_GRAPH, 0)
+s.update(); s.sync()
+import time
+t0 = time.perf_counter()
+L.check(lib.fs_timer_begin(s.ctx), s.ctx)
+for f in range(50):
+    s.update()
+t1 = time.perf_counter()
+L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
+print("update() eager     %8.1f us  (host enqueue %.1f us per frame)" % (ms.value * 1e3 / 50, (t1 - t0) * 1e6 / 50))
