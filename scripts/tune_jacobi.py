@@ -20,8 +20,9 @@ names = {0: "8x8", 1: "16x8", 2: "8x16", 3: "16x4", 4: "4x16", 5: "12x8"}
 th = {0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 96}
 ms = C.c_float()
 res = []
-for var in range(6):
-    for depth in (4, 5, 7, 8, 10, 14, 20):
+VARS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else range(6)
+for var in VARS:
+    for depth in (5, 7, 8, 10, 12, 14, 16, 20):
         if th[var] - 2 * depth < 8:
             continue
         L.check(lib.fs_config_set(L.OPT_TILE_VARIANT, var)); L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
