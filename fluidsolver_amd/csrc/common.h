@@ -48,6 +48,39 @@ __device__ __forceinline__ bool is_boundary(const GK &g, int x, int y)
     // gid.x == 0 || gid.x >= width-1 || gid.y == 0 || gid.y >= height-1  (e.g. Shaders:91)
     return x == 0 || x >= g.W - 1 || y == 0 || y >= g.H - 1;
 }
+// XCD-aware tile index.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order (observed
+// behaviour, not a contract: it is used here for L2 affinity only, never for correctness), so with the
+// plain blockIdx mapping the tiles that share halo rows and columns sit on different L2s and each
+// fetches them from the Infinity Cache / HBM again.  Here the tile rows are cut into bands of M tile
+// rows and the bands are dealt to the XCDs in turn: the tiles of a band share one L2, while the eight
+// XCDs still sweep the same 8*M tile rows of the grid together (giving every XCD one large contiguous
+// chunk instead was measured slower at 16384^2: eight distant DRAM streams).
+// The launch pads gridDim.y to a multiple of 8*M (xcd_pad_rows); tiles past the real grid exit.
+template <int M>
+__device__ __forceinline__ uint2 xcd_tile()
+{
+    const unsigned gx = gridDim.x;
+    const unsigned lin = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned per_band = gx * M;
+    const unsigned b = idx / per_band, w = idx - b * per_band;
+    const unsigned wy = w / gx;
+    return make_uint2(w - wy * gx, (b * 8u + xcd) * M + wy);
+}
+// The other extreme: every XCD gets ONE contiguous chunk of the (y, x) tile order (bijective for any grid).
+// Pays only while the whole working set sits in the Infinity Cache (see jacobi.hip).
+__device__ __forceinline__ uint2 xcd_tile_chunked()
+{
+    const unsigned gx = gridDim.x, total = gx * gridDim.y;
+    const unsigned lin = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned t = xcd * q + (xcd < r ? xcd : r) + idx;
+    const unsigned y = t / gx;
+    return make_uint2(t - y * gx, y);
+}
+inline unsigned xcd_pad_rows(unsigned tile_rows, unsigned m) { return (tile_rows + 8u * m - 1u) / (8u * m) * (8u * m); }
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

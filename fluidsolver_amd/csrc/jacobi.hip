@@ -39,6 +39,7 @@ struct JacobiArgs {
     int HX;            // horizontal halo, multiple of 4, >= T
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
+    int xcd_chunked;   // tile order, see the kernel
     int stagger;       // start delay of every other resident workgroup, 10 ns ticks (0 = off)
     int stagger_mode;
 };
@@ -172,8 +173,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     }
     const int OW = TW - 2 * A.HX;
     const int OH = TH - 2 * A.T;
-    const int x0 = blockIdx.x * OW - A.HX;               // tile column 0 (global), multiple of 4
-    const int ry0 = A.yb + blockIdx.y * OH - A.T;        // tile row 0 (global)
+    // Tile order.  Plain blockIdx by default; for a pressure loop whose three planes fit the Infinity Cache
+    // each XCD takes one contiguous chunk of the grid, so the overlapping tile rims hit in its L2 (3072^2:
+    // 143 -> 128 us per 40 sweeps; at 16384^2, HBM-bound, the same remap costs 4 %: eight distant streams).
+    const uint2 tile = A.xcd_chunked ? xcd_tile_chunked() : make_uint2(blockIdx.x, blockIdx.y);
+    const int x0 = tile.x * OW - A.HX;                   // tile column 0 (global), multiple of 4
+    const int ry0 = A.yb + tile.y * OH - A.T;            // tile row 0 (global)
     const int gx = x0 + 4 * lane;                        // this lane's first column
     const int wy0 = ry0 + wave * R;                      // this wave's first row
     const size_t plane = (size_t)blockIdx.z * A.stride;
@@ -267,6 +272,8 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.rden = 1.0 / (double)den;
     A.stagger = g_stagger;
     A.stagger_mode = g_stagger_mode;
+    // p in, p out and div of the rows in play, against ~3/4 of the 256 MiB Infinity Cache
+    A.xcd_chunked = OP == OP_PRESSURE && 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) < 192.0 * 1024 * 1024;
     switch (g_tile_variant) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads

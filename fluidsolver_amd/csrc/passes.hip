@@ -18,17 +18,20 @@ namespace fs {
 
 constexpr int BX = 64;  // lanes along x (each 4 cells)
 constexpr int BY = 4;   // rows per workgroup
+constexpr int XCD_BAND = 8;   // tile rows per XCD band (32 grid rows), see xcd_tile
 
 struct Quad {
-    int x, y;
+    int x, y, z;   // first cell of the quad, row, plane
     bool ok;
 };
 
 __device__ __forceinline__ Quad quad_of_thread(const GK &g, int yb, int ye)
 {
+    const uint2 t = xcd_tile<XCD_BAND>();
     Quad q;
-    q.x = (blockIdx.x * BX + threadIdx.x) * 4;
-    q.y = yb + blockIdx.y * BY + threadIdx.y;
+    q.x = (t.x * BX + threadIdx.x) * 4;
+    q.y = yb + t.y * BY + threadIdx.y;
+    q.z = blockIdx.z;
     q.ok = q.x < g.pitch && q.y < ye;
     return q;
 }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void k_fade(GK g, int yb, int ye, float *__res
 {
     Quad q = quad_of_thread(g, yb, ye);
     if (!q.ok) return;
-    float *p = d + (size_t)blockIdx.z * stride + row_off(g, q.y) + q.x;
+    float *p = d + (size_t)q.z * stride + row_off(g, q.y) + q.x;
     float4 x = ld4(p);
     x.x = fmaxf(x.x * k, 0.0f);
     x.y = fmaxf(x.y * k, 0.0f);
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_clear(GK g, int yb, int ye, float *__re
 {
     Quad q = quad_of_thread(g, yb, ye);
     if (!q.ok) return;
-    st4(t + (size_t)blockIdx.z * stride + row_off(g, q.y) + q.x, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4(t + (size_t)q.z * stride + row_off(g, q.y) + q.x, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // ---------------------------------------------------------------------------
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const flo
 static inline dim3 quad_grid(const fs_grid *g, int nplanes)
 {
     int qx = g->pitch / 4;
-    return dim3((qx + BX - 1) / BX, (g->ye - g->yb + BY - 1) / BY, nplanes);
+    return dim3((qx + BX - 1) / BX, xcd_pad_rows((g->ye - g->yb + BY - 1) / BY, XCD_BAND), nplanes);
 }
 static const dim3 kBlock(BX, BY, 1);
 
