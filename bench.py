@@ -122,6 +122,47 @@ def cpu_baseline(W, H, params, budget_s=20.0):
                 frames_per_s=fps, host_cpus=os.cpu_count())
 
 
+def slab_selfcheck(dist, rank, world, local_rank):
+    """N > 1 only: a small grid stepped as `world` row slabs over RCCL must equal the same grid stepped on
+    one GPU, bit for bit (velocity, dye, pressure).  Untimed; the verdict goes into the JSON line."""
+    import torch
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import RcclSlab
+    from fluidsolver_amd.script import splat
+    W, H, frames = 640, 96 * world, 4
+    params = (1.5e-4, 0.00001, 0.5, 10.0, 0.002, 12)
+    s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
+    for f in range(frames):
+        s.frame(5 * f + 1, n_pointers=world, forceMultiplier=2.0)
+    s.sync()
+    mine = np.concatenate([s.owned("vel"), s.owned("dye"), s.owned("p")], axis=0)   # [6, H/world, W]
+    halo = s.last_halo
+    s.close()
+    t = torch.from_numpy(np.ascontiguousarray(mine))
+    parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, parts, dst=0)
+    verdict = [""]
+    if rank == 0:
+        got = np.concatenate([p.numpy() for p in parts], axis=1)
+        ref = FluidSolver(W, H, device=local_rank)
+        (ref.viscosity, ref.diffusion, ref.deltaTime, ref.vorticityStrength, ref.fadeSpeed, ref.solverIterations) = params
+        ref.displayMode = None
+        for f in range(frames):
+            for ptr in range(world):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, world, 2.0)
+                ref.applyForce(pos, force, col)
+            ref.update()
+        ref.sync()
+        exp = np.concatenate([ref.read_field(L.FIELD_VELOCITY), ref.read_field(L.FIELD_DENSITY),
+                              ref.read_field(L.FIELD_PRESSURE)], axis=0)
+        ref.close()
+        same = np.array_equal(got, exp) and bool(np.abs(exp[:2]).max() > 0)
+        verdict[0] = ("bit-identical to 1 GPU" if same else "MISMATCH against 1 GPU (%d cells differ)"
+                      % int((got != exp).sum())) + " on %dx%d, %d frames, advection halo %d rows" % (W, H, frames, halo)
+    dist.broadcast_object_list(verdict, src=0)
+    return verdict[0]
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/traffic.json,
     collected on config 2 by scripts/profile_round.sh); null for any other workload."""
@@ -165,7 +206,10 @@ def main():
     W, Hg = wl["W"], wl["H"]
     params = wl["params"]
 
-    if world == 1:
+    # FS_BENCH_FORCE_SLABS=1 (test hook): take the multi-rank code path with a single rank, so that the
+    # control plane, the slab self-check and the JSON of an N > 1 run can be rehearsed on a 1-GPU box.
+    slabs = world > 1 or os.environ.get("FS_BENCH_FORCE_SLABS") == "1"
+    if not slabs:
         H = Hg
         s, ps = make_single(W, H, params, wl["particles"])
         n_ptr = wl.get("pointers", 1)
@@ -183,6 +227,7 @@ def main():
         H = Hg * world if wl["scaling"] == "weak" else Hg
         s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
         L.check(lib.fs_comm_selftest(s.comm, 1 << 16))
+        slab_check = slab_selfcheck(dist, rank, world, local_rank)
         n_ptr = wl.get("pointers", world)   # weak scaling: one pointer per slab; config 4: always eight
         step = lambda f: s.frame(f, n_pointers=n_ptr)   # noqa: E731
         barrier = dist.barrier
@@ -202,7 +247,7 @@ def main():
     barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if slabs:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -228,7 +273,7 @@ def main():
         "frames_per_s": fps,
     }
 
-    if world == 1:
+    if not slabs:
         alg = ALG_BYTES_FRAME_CONFIG2 if params[5] == 40 else None
         if alg:
             out["frame_effective_GBps"] = alg * total_cells * fps / 1e9
@@ -246,14 +291,14 @@ def main():
                                    "effective figure may exceed the HBM peak"}
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
-    if world > 1:
+    if slabs:
         st = s.stats
-        out["slab"] = {"rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+        out["slab"] = {"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"]))}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if slabs:
         dist.destroy_process_group()
 
 
