@@ -203,8 +203,19 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(cfl)");
     }
     if (!rc) {
-        e = hipHostMalloc((void **)&c->cfl_host, sizeof(float), hipHostMallocDefault);
+        e = hipHostMalloc((void **)&c->cfl_host, (size_t)world * sizeof(float), hipHostMallocDefault);
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipHostMalloc(cfl)");
+    }
+    if (!rc && world > 1) {
+        // exchange stream and its events (slab.hip)
+        e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cfl, hipEventDisableTiming);
+        for (int i = 0; i < SLOT_COUNT && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_slot[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) rc = fs::hip_fail(e, "exchange stream / events");
     }
     for (int i = 0; i < 7 && !rc && max_particles > 0; ++i) {
         e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
@@ -262,9 +273,10 @@ int fs_destroy(fs_ctx *c)
     if (!c) return FS_OK;
     if (c->dry) { delete c; return FS_OK; }
     (void)hipSetDevice(c->device);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graphs(c);
-    if (c->comm && c->comm->kind == 0 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
+    if (c->comm && c->comm->kind != 1 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
         c->comm->members[c->rank] = nullptr;
     for (int i = 0; i < F_COUNT; ++i) { (void)hipFree(c->f[i].buf[0]); (void)hipFree(c->f[i].buf[1]); }
     (void)hipFree(c->display); (void)hipFree(c->err_flag); (void)hipFree(c->cfl_dev);
@@ -272,6 +284,13 @@ int fs_destroy(fs_ctx *c)
     for (int i = 0; i < 7; ++i) (void)hipFree(c->part[i]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_cfl) (void)hipEventDestroy(c->ev_cfl);
+    for (int i = 0; i < SLOT_COUNT; ++i) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_slot[i]) (void)hipEventDestroy(c->ev_slot[i]);
+    }
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FS_OK;
@@ -290,6 +309,7 @@ int fs_reset(fs_ctx *c)
     }
     TRYHIP(c, hipMemsetAsync(c->display, 0, 4 * pb, c->stream));
     TRYHIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
+    c->last_true_halo = -1;
     return FS_OK;
 }
 
@@ -326,6 +346,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
         break;
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
     case FS_OPT_FUSE: c->fuse = value ? 1 : 0; break;
+    case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:
         if (fs::config_set_tile_variant(value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
@@ -413,6 +434,7 @@ int fs_step(fs_ctx *c)
 int fs_sync(fs_ctx *c)
 {
     CTX(c);
+    if (c->xstream) TRYHIP(c, hipStreamSynchronize(c->xstream));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     int flag = 0;
     TRYHIP(c, hipMemcpy(&flag, c->err_flag, sizeof(int), hipMemcpyDeviceToHost));

@@ -30,7 +30,10 @@ struct Xfer {
     int field, bufidx, depth;   // refresh the ghost rows of f[field].buf[bufidx] to `depth` rows
 };
 
-enum { STEP_COMPUTE = 0, STEP_EXCHANGE = 1, STEP_CFL_REDUCE = 2 };
+enum { STEP_COMPUTE = 0, STEP_EXCHANGE = 1, STEP_CFL_REDUCE = 2, STEP_JOIN = 3 };
+// An exchange runs on the context's exchange stream.  Its completion event is a "slot"; the main
+// stream joins a slot (waits for the event) before the first kernel that needs the rows.
+enum { SLOT_VEL = 0, SLOT_DYE = 1, SLOT_SYNC = 2, SLOT_COUNT = 3 };
 
 // One entry of a frame plan.  The plan of a frame is the same on every rank (same kinds, same
 // depths), which is what lets an in-process group run K slabs in lock step.
@@ -40,15 +43,20 @@ struct Step {
     int yb = 0, ye = 0, n = 0;          // rows computed / sweeps (plan dumps, tests)
     std::function<int()> run;           // STEP_COMPUTE: enqueue the kernel(s) on the context's stream
     std::vector<Xfer> xf;               // STEP_EXCHANGE
+    int slot = SLOT_SYNC;               // STEP_EXCHANGE / STEP_JOIN
+    bool async = false;                 // STEP_EXCHANGE: do not join right away (a STEP_JOIN follows later)
 };
 
 void slab_rows(int H, int world, int rank, int *r0, int *r1);
 
 }  // namespace fs
 
-// Transport of the halo exchange.  kind 1 = RCCL (one process per GPU, ncclSend/ncclRecv over xGMI);
-// kind 0 = in-process group (all slabs live in this process; copies are plain device memcpys) used
-// to test the slab logic on a 1-GPU box.
+// Transport of the halo exchange.  kind 1 = RCCL (one process per GPU, ncclSend/ncclRecv over xGMI).
+// kinds 0 and 2 = in-process groups (all slabs live in this process) used to test the slab logic on a
+// 1-GPU box: kind 0 copies with blocking device memcpys between full synchronisations (the simplest
+// possible transport); kind 2 copies asynchronously on the exchange streams, ordered only by the
+// same events the RCCL path uses, so the K slabs really run concurrently and a missing dependency
+// shows up as a wrong result.
 struct fs_comm {
     int kind = 0;
     int world = 1;
@@ -74,8 +82,17 @@ struct fs_ctx {
     float *display = nullptr;           // 4 planes
     int *err_flag = nullptr;            // device
     float *cfl_dev = nullptr;           // device: max |v_y| of the owned rows
-    float *cfl_host = nullptr;          // pinned
+    float *cfl_host = nullptr;          // pinned, `world` floats (RCCL uses the first)
     float cfl_max = 0.0f;               // all-reduced value of the current frame
+    // exchange stream: every halo transfer and the CFL reduction run here, next to the kernels
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_main = nullptr;       // main stream: "rows are final" (what a transfer waits for)
+    hipEvent_t ev_copied[fs::SLOT_COUNT] = {nullptr, nullptr, nullptr};   // kind 2: my receives are done
+    hipEvent_t ev_slot[fs::SLOT_COUNT] = {nullptr, nullptr, nullptr};     // transfer complete (sends and receives)
+    bool pending[fs::SLOT_COUNT] = {false, false, false};
+    hipEvent_t ev_cfl = nullptr;        // CFL value has landed in cfl_host
+    int overlap = 1;                    // FS_OPT_SLAB_OVERLAP: speculative halo + split advection
+    int last_true_halo = -1;            // advection halo the previous frame really needed (-1: unknown)
     fs_params params{};
     int use_graph = 1;
     int with_particles = 0;
@@ -85,7 +102,7 @@ struct fs_ctx {
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
     std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
     // statistics of the slab path
-    long stat_exchanges = 0, stat_rows = 0, stat_frames = 0;
+    long stat_exchanges = 0, stat_rows = 0, stat_frames = 0, stat_redo = 0;
     int last_halo = 0;
     // tracers
     long max_particles = 0, n_particles = 0;
@@ -101,12 +118,11 @@ int ctx_fail(fs_ctx *c, int rc);
 fs_grid grid_of(const fs_ctx *c, int depth);
 
 // frame planner (slab.hip)
-void plan_update_a(fs_ctx *c);          // update() up to subtractGradient (+ the CFL reduction on slabs)
+void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient (+ the CFL reduction on slabs);
+                                             // h_spec >= 0: prefetch the dye halo of that depth
 void plan_update_b(fs_ctx *c, int h);   // advection .. particles, with advection halo h
-int exec_step(fs_ctx *c, const Step &s);
 int run_frame(fs_ctx *c);               // plan + execute one update() on this context (world 1 or RCCL)
-int comm_exchange(fs_ctx *c, const std::vector<Xfer> &xf);
-int comm_allreduce_max(fs_ctx *c);
+int run_frames(fs_ctx **cs, int n);     // ... on all n slabs of an in-process group, in lock step
 
 }  // namespace fs
 

@@ -99,11 +99,9 @@ __global__ __launch_bounds__(256) void k_vorticity(GK g, int yb, int ye, const f
 // ---------------------------------------------------------------------------
 // subtractGradient, Shaders:225-245: vel.x -= 0.5*(r-l); vel.y -= 0.5*(b-t); boundary untouched
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_subtract_gradient(GK g, int yb, int ye, const float *__restrict__ p,
-                                                           float *__restrict__ u, float *__restrict__ v)
+__device__ __forceinline__ float subtract_gradient_quad(const GK &g, const Quad &q, const float *__restrict__ p,
+                                                        float *__restrict__ u, float *__restrict__ v)
 {
-    Quad q = quad_of_thread(g, yb, ye);
-    if (!q.ok) return;
     RowN pn = load_row_nb(p, g, q.x, q.y);
     float4 pt = ld4(p + row_off(g, clamp_row(g, q.y - 1)) + q.x);
     float4 pb = ld4(p + row_off(g, clamp_row(g, q.y + 1)) + q.x);
@@ -116,6 +114,39 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(GK g, int yb, int ye,
     if (!is_boundary(g, q.x + 3, q.y)) { uu.w = uu.w - 0.5f * (pr.w - pl.w); vv.w = vv.w - 0.5f * (pb.w - pt.w); }
     st4(u + o, uu);
     st4(v + o, vv);
+    // |v| of the cells inside the domain (padding columns are don't-care)
+    float m = fabsf(vv.x);
+    if (q.x + 1 < g.W) m = fmaxf(m, fabsf(vv.y));
+    if (q.x + 2 < g.W) m = fmaxf(m, fabsf(vv.z));
+    if (q.x + 3 < g.W) m = fmaxf(m, fabsf(vv.w));
+    return q.x < g.W ? m : 0.0f;
+}
+
+// CFL: also max |v| of the new v plane over the launch (in-domain columns only), one atomicMax per
+// workgroup (non-negative floats order like their bit patterns).
+template <bool CFL>
+__global__ __launch_bounds__(256) void k_subtract_gradient(GK g, int yb, int ye, const float *__restrict__ p,
+                                                           float *__restrict__ u, float *__restrict__ v,
+                                                           unsigned *__restrict__ cfl)
+{
+    __shared__ float wave_max[4];
+    Quad q = quad_of_thread(g, yb, ye);
+    if (CFL) {
+        // every thread of the workgroup reaches the barrier: out-of-range quads contribute 0
+        float m = 0.0f;
+        if (q.ok) m = subtract_gradient_quad(g, q, p, u, v);
+        for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+        const int tid = threadIdx.y * BX + threadIdx.x;
+        if ((tid & 63) == 0) wave_max[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+            if (m > 0.0f) atomicMax(cfl, __float_as_uint(m));
+        }
+        return;
+    }
+    if (!q.ok) return;
+    (void)subtract_gradient_quad(g, q, p, u, v);
 }
 
 // ---------------------------------------------------------------------------
@@ -438,8 +469,20 @@ int fs_k_subtractGradient(const fs_grid *g, const float *p, float *u, float *v, 
     CHECK_GRID(g);
     REQUIRE(p && u && v, "null pointer");
     EMPTY_OK(g);
-    hipLaunchKernelGGL(k_subtract_gradient, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, p, u, v);
+    hipLaunchKernelGGL(k_subtract_gradient<false>, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, p, u, v,
+                       (unsigned *)nullptr);
     FS_LAUNCH_CHECK("k_subtract_gradient");
+    return FS_OK;
+}
+
+int fs_k_subtractGradient_cfl(const fs_grid *g, const float *p, float *u, float *v, float *cfl_dev, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(p && u && v && cfl_dev, "null pointer");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_subtract_gradient<true>, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, p, u, v,
+                       reinterpret_cast<unsigned *>(cfl_dev));
+    FS_LAUNCH_CHECK("k_subtract_gradient_cfl");
     return FS_OK;
 }
 

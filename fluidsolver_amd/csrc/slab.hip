@@ -14,7 +14,20 @@
 //     beat one per sweep, and the redundant ghost-row compute is cheap.
 //   * The semi-Lagrangian backtrace is clamped only to the domain (Shaders:133-137), so the advection
 //     halo is sized per frame from the CFL bound: h = ceil(max|v_y| dt) + 2, max over all ranks (one
-//     4-byte all-reduce + one host sync per frame).
+//     4-byte all-reduce per frame).
+//   * Overlap (FS_OPT_SLAB_OVERLAP, default on).  Measured on the scripted workloads the advection halo
+//     is 15-50 rows at 3072^2 and 70-170 rows at 16384^2 (profiles/r01_probe_cfl.log): tens of MB per
+//     neighbour and frame, too much to leave on the critical path.  So (1) every transfer runs on a
+//     second stream and the kernels wait for it by event only where they need the rows; (2) the
+//     velocity advection also computes the 2N+3 ghost rows the NEXT frame's stencil chain needs (same
+//     kernel, same inputs as the owner => same bits), so the frame-start exchange disappears into the
+//     pre-advection one (depth h + 2N+3); (3) advection is split into interior rows, whose backtrace
+//     cannot leave the owned rows, and two rims: the interior of the velocity and of the dye run while
+//     the halo is in flight; (4) the halo depth is SPECULATED from the previous frame (1.25 h + 4), so
+//     the dye halo is fetched at frame start, under the whole stencil chain, and the host never waits
+//     for the CFL value before enqueueing; advection writes to the ping-pong partner, so when the
+//     all-reduced bound turns out larger than the guess the advection part of the frame is simply
+//     planned again with the true depth (stat_redo counts it).
 //
 // A frame is first PLANNED (pure host bookkeeping of ghost depths and ping-pong roles; identical on
 // every rank) into a list of steps -- kernel launches, exchanges, the CFL reduction -- then executed.
@@ -70,24 +83,60 @@ struct Planner {
         c->steps.push_back(std::move(s));
     }
 
-    // refresh, in ONE batched round, every listed field whose valid depth is short (capped at G)
-    void ensure(std::initializer_list<std::pair<int, int>> wants)
+    // refresh, in ONE batched round, every listed field whose valid depth is short (capped at G);
+    // async: the main stream does not wait here, a join(slot) is planned where the rows are needed
+    bool ensure(std::initializer_list<std::pair<int, int>> wants, int slot = SLOT_SYNC, bool async = false)
     {
-        if (!multi) return;
+        if (!multi) return false;
         Step s;
         s.kind = STEP_EXCHANGE;
-        s.what = "exchange";
+        s.what = async ? "exchange_async" : "exchange";
+        s.slot = slot;
+        s.async = async;
         for (const auto &w : wants) {
             const int d = std::min(w.second, G);
             if (c->f[w.first].valid < d) s.xf.push_back(Xfer{w.first, c->f[w.first].cur, d});
         }
-        if (s.xf.empty()) return;
+        if (s.xf.empty()) return false;
         for (const auto &x : s.xf) c->f[x.field].valid = x.depth;
         c->steps.push_back(std::move(s));
+        return true;
     }
     void need(int f, int depth)
     {
         if (multi && c->f[f].valid < std::min(depth, G)) ensure({{f, depth}});
+    }
+    void join(int slot)
+    {
+        Step s;
+        s.kind = STEP_JOIN;
+        s.what = slot == SLOT_VEL ? "join vel" : "join dye";
+        s.slot = slot;
+        c->steps.push_back(std::move(s));
+    }
+    // rows [yb, ye) clipped to the buffer (possibly empty)
+    fs_grid grid_rows(int yb, int ye) const
+    {
+        yb = std::max(yb, c->b0);
+        ye = std::min(ye, c->b1);
+        if (ye < yb) ye = yb;
+        return fs_grid{c->W, c->H, c->pitch, c->b0, c->b1 - c->b0, yb, ye};
+    }
+    // ghost depth of velocity the stencil chain of update() consumes, backwards from subtractGradient
+    // on the owned rows: p(1) <- N sweeps <- div(N) <- vel(N+1) <- N diffuse sweeps <- vel(2N+1)
+    // <- applyVorticity <- vort(2N+2) <- vel(2N+3)
+    struct Needs { int p, div, v2, v1, v0; };
+    Needs chain_needs() const
+    {
+        const fs_params &p = c->params;
+        const int N = p.solverIterations;
+        Needs n;
+        n.p = 1;
+        n.div = n.p + std::max(N - 1, 0);
+        n.v2 = n.div + 1;
+        n.v1 = n.v2 + (p.viscosity > 0.0f ? N : 0);
+        n.v0 = n.v1 + (p.vorticityStrength > 0.0f ? 2 : 0);
+        return n;
     }
 
     // N Jacobi sweeps on field fi (ping-pong).  One sweep computed on the owned rows +- d reads the
@@ -147,11 +196,13 @@ struct Planner {
         }
     }
 
-    void advect(int fi, bool fade)
+    // advect field fi on rows [yb, ye) (no role swap: the caller swaps once all parts are planned)
+    void advect_rows(int fi, bool fade, int yb, int ye)
     {
         Field &F = c->f[fi];
-        const fs_grid g = grid_of(c, 0);
-        const float *u = c->f[F_VEL].p(), *v = u + c->plane;
+        const fs_grid g = grid_rows(yb, ye);
+        const bool vel_done = fi != F_VEL;   // the dye is traced through the advected velocity (Solver:577-582)
+        const float *u = vel_done ? c->f[F_VEL].p() : F.p(), *v = u + c->plane;
         const float *src = F.p();
         float *dst = F.t();
         const int np = F.np;
@@ -163,12 +214,17 @@ struct Planner {
             compute("advect_fade", g, np, [=]() { return fs_k_advect_fade(&g, u, v, src, dst, np, plane, dt, fr, err, st); });
         else
             compute("advect", g, np, [=]() { return fs_k_advect(&g, u, v, src, dst, np, plane, dt, err, st); });
-        F.cur ^= 1;                                                                   // Solver:558, :584
-        if (multi) F.valid = 0;
+    }
+    void advect(int fi, bool fade, int depth = 0)
+    {
+        advect_rows(fi, fade, c->r0 - depth, c->r1 + depth);
+        c->f[fi].cur ^= 1;                                                            // Solver:558, :584
+        if (multi) c->f[fi].valid = depth;
     }
 
-    // update() up to subtractGradient, Solver:486-547
-    void plan_a()
+    // update() up to subtractGradient, Solver:486-547.  h_spec >= 0: the advection halo this frame is
+    // expected to need; the dye halo of that depth is fetched now, under the whole stencil chain.
+    void plan_a(int h_spec)
     {
         const fs_params &p = c->params;
         const int N = p.solverIterations;
@@ -176,16 +232,11 @@ struct Planner {
         const bool vort_on = p.vorticityStrength > 0.0f, visc_on = p.viscosity > 0.0f;
         hipStream_t st = c->stream;
         const size_t plane = c->plane;
-        // ghost depths the velocity chain needs, backwards from subtractGradient on the owned rows:
-        // p(1) <- N sweeps <- div(N) <- vel(N+1) <- N diffuse sweeps <- vel(2N+1) <- applyVorticity
-        // <- vort(2N+2) <- vel(2N+3)
-        const int need_p = 1;
-        const int need_div = need_p + std::max(N - 1, 0);
-        const int need_v2 = need_div + 1;
-        const int need_v1 = need_v2 + (visc_on ? N : 0);
-        const int need_v0 = need_v1 + (vort_on ? 2 : 0);
+        const Needs nd = chain_needs();
+        const int need_p = nd.p, need_div = nd.div, need_v2 = nd.v2, need_v1 = nd.v1, need_v0 = nd.v0;
         Field &V = c->f[F_VEL];
 
+        if (multi && h_spec >= 0) ensure({{F_DYE, h_spec}}, SLOT_DYE, true);
         if (vort_on) {                                                                // :486-502
             need(F_VEL, need_v0);
             const int dw = multi ? std::min(need_v1 + 1, eff(F_VEL) - 1) : 0;
@@ -229,19 +280,21 @@ struct Planner {
         {
             const fs_grid g = grid_of(c, 0);
             float *u = V.p(), *v = u + plane, *pp = c->f[F_P].p();
-            compute("subtractGradient", g, 0, [=]() { return fs_k_subtractGradient(&g, pp, u, v, st); }); // :544-547
+            if (!multi) {
+                compute("subtractGradient", g, 0, [=]() { return fs_k_subtractGradient(&g, pp, u, v, st); }); // :544-547
+            } else {
+                // ... and, in the same pass, the CFL bound of the backtrace: max |v_y| over the owned rows
+                float *cfl = c->cfl_dev;
+                compute("subtractGradient_cfl", g, 0, [=]() {
+                    hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
+                    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
+                    return fs_k_subtractGradient_cfl(&g, pp, u, v, cfl, st);
+                });
+            }
         }
         if (multi) {
             V.valid = 0;
-            // CFL bound of the backtrace: max |v_y| over the owned rows, then max over ranks
-            const fs_grid g = grid_of(c, 0);
-            float *v = V.p() + plane, *cfl = c->cfl_dev;
-            compute("max_abs", g, 0, [=]() {
-                hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
-                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
-                return fs_k_max_abs(&g, v, cfl, st);
-            });
-            Step s;
+            Step s;                                                                   // ... then max over ranks
             s.kind = STEP_CFL_REDUCE;
             s.what = "cfl_allreduce";
             c->steps.push_back(std::move(s));
@@ -256,16 +309,40 @@ struct Planner {
         const int ddn = (p.diffusion > 0.0f && N > 0) ? N : 0;
         hipStream_t st = c->stream;
         const size_t plane = c->plane;
-        if (multi) ensure({{F_VEL, h}, {F_DYE, h + ddn}});                            // one batched round
-        advect(F_VEL, false);                                                         // :550-558
-        if (ddn) {                                                                    // :562-574
-            sweeps(false, F_DYE, N, h);
-            need(F_DYE, h);
-        }
-        if (c->fuse) {
-            advect(F_DYE, true);                                                      // :577-591 in one pass
+        // overlap: the advected velocity is also computed on the ghost rows the next frame's stencil
+        // chain consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
+        const int adv = (multi && c->overlap) ? std::max(0, std::min(chain_needs().v0, G - h)) : 0;
+        const bool split = multi && c->overlap && ddn == 0 && c->H / c->world > 2 * h + 8;
+        if (split) {
+            ensure({{F_VEL, h + adv}, {F_DYE, h}}, SLOT_VEL, true);                   // dye: normally prefetched by plan_a
+            const int i0 = c->r0 + (c->r0 > 0 ? h : 0), i1 = c->r1 - (c->r1 < c->H ? h : 0);
+            // interior rows: no tap of their backtrace leaves the owned rows            :550-558, :577-591
+            advect_rows(F_VEL, false, i0, i1);
+            c->f[F_VEL].cur ^= 1;
+            advect_rows(F_DYE, c->fuse != 0, i0, i1);
+            c->f[F_VEL].cur ^= 1;
+            join(SLOT_VEL);
+            advect_rows(F_VEL, false, c->r0 - adv, i0);
+            advect_rows(F_VEL, false, i1, c->r1 + adv);
+            c->f[F_VEL].cur ^= 1;                                                     // :558
+            c->f[F_VEL].valid = adv;
+            join(SLOT_DYE);
+            advect_rows(F_DYE, c->fuse != 0, c->r0, i0);
+            advect_rows(F_DYE, c->fuse != 0, i1, c->r1);
+            c->f[F_DYE].cur ^= 1;                                                     // :584
         } else {
-            advect(F_DYE, false);                                                     // :577-584
+            if (multi) {
+                ensure({{F_VEL, h + adv}, {F_DYE, h + ddn}});                         // one batched round
+                join(SLOT_DYE);                                                       // a prefetch of plan_a, if any
+            }
+            advect(F_VEL, false, adv);                                                // :550-558
+            if (ddn) {                                                                // :562-574
+                sweeps(false, F_DYE, N, h);
+                need(F_DYE, h);
+            }
+            advect(F_DYE, c->fuse != 0);                                              // :577-584 (+ :587-591 when fused)
+        }
+        if (!c->fuse) {
             const fs_grid g = grid_of(c, 0);
             float *d = c->f[F_DYE].p();
             const float fr = p.fadeSpeed;
@@ -415,82 +492,154 @@ int sync_members(const fs_comm *cm)
 
 }  // namespace
 
-void plan_update_a(fs_ctx *c) { Planner(c).plan_a(); }
+void plan_update_a(fs_ctx *c, int h_spec) { Planner(c).plan_a(h_spec); }
 void plan_update_b(fs_ctx *c, int h) { Planner(c).plan_b(h); }
 
-int comm_exchange(fs_ctx *c, const std::vector<Xfer> &xf)
+namespace {
+
+int join_slot(fs_ctx *c, int slot)
+{
+    if (!c->pending[slot]) return FS_OK;
+    FS_HIP(hipStreamWaitEvent(c->stream, c->ev_slot[slot], 0));
+    c->pending[slot] = false;
+    return FS_OK;
+}
+
+// One halo exchange, in three phases so that an in-process group can walk them in lock step (phase p
+// of every rank before phase p+1 of any); a rank of an RCCL run just runs them back to back.
+//   0  main stream: "my rows are final" (ev_main)
+//   1  exchange stream: wait for that (and, kind 2, for the peers' rows), move the rows
+//   2  kind 2: my sends are complete once the peers have copied; the main stream joins unless async
+int exchange_phase(fs_ctx *c, const Step &st, int phase)
 {
     fs_comm *cm = c->comm;
     if (!cm) { set_error("exchange planned on a context without a communicator"); return FS_ERR_STATE; }
     std::vector<Seg> segs;
-    build_segments(c, xf, segs);
-    c->stat_exchanges += 1;
-    for (const Seg &s : segs)
-        if (s.send) c->stat_rows += s.y1 - s.y0;
-    if (cm->kind == 1) {
-        FS_NCCL(g_rccl.GroupStart());
-        for (const Seg &s : segs) {
-            const size_t count = (size_t)(s.y1 - s.y0) * c->pitch;
-            ncclResult_t r = s.send ? g_rccl.Send(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->stream)
-                                    : g_rccl.Recv(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->stream);
-            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(r, s.send ? "ncclSend" : "ncclRecv"); }
-        }
-        FS_NCCL(g_rccl.GroupEnd());
+    build_segments(c, st.xf, segs);
+    if (phase == 0) {
+        c->stat_exchanges += 1;
+        for (const Seg &s : segs)
+            if (s.send) c->stat_rows += s.y1 - s.y0;
+        if (cm->kind != 0) FS_HIP(hipEventRecord(c->ev_main, c->stream));
         return FS_OK;
     }
-    // in-process group: every rank's owned rows are final when its turn comes (lock step), ghost rows
-    // are only written here; plain blocking copies between full synchronisations
-    int rc = sync_members(cm);
-    if (rc) return rc;
-    FS_HIP(hipSetDevice(c->device));
-    for (const Seg &s : segs) {
-        if (s.send) continue;
-        const fs_ctx *peer = cm->members[s.peer];
-        FS_HIP(hipMemcpy(seg_ptr(c, s), seg_ptr(peer, s), (size_t)(s.y1 - s.y0) * c->pitch * sizeof(float),
-                         hipMemcpyDeviceToDevice));
+    if (phase == 1) {
+        if (cm->kind == 1) {
+            FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
+            FS_NCCL(g_rccl.GroupStart());
+            for (const Seg &s : segs) {
+                const size_t count = (size_t)(s.y1 - s.y0) * c->pitch;
+                ncclResult_t r = s.send ? g_rccl.Send(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->xstream)
+                                        : g_rccl.Recv(seg_ptr(c, s), count, ncclFloat, s.peer, (ncclComm_t)cm->nccl, c->xstream);
+                if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(r, s.send ? "ncclSend" : "ncclRecv"); }
+            }
+            FS_NCCL(g_rccl.GroupEnd());
+            FS_HIP(hipEventRecord(c->ev_slot[st.slot], c->xstream));
+            return FS_OK;
+        }
+        if (cm->kind == 2) {
+            FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
+            int last = -1;
+            for (const Seg &s : segs) {
+                if (s.send) continue;
+                const fs_ctx *peer = cm->members[s.peer];
+                if (s.peer != last) FS_HIP(hipStreamWaitEvent(c->xstream, peer->ev_main, 0));
+                last = s.peer;
+                FS_HIP(hipMemcpyAsync(seg_ptr(c, s), seg_ptr(peer, s), (size_t)(s.y1 - s.y0) * c->pitch * sizeof(float),
+                                      hipMemcpyDeviceToDevice, c->xstream));
+            }
+            FS_HIP(hipEventRecord(c->ev_copied[st.slot], c->xstream));
+            return FS_OK;
+        }
+        // kind 0: every rank's owned rows are final when its turn comes (lock step), ghost rows are
+        // only written here; plain blocking copies between full synchronisations
+        int rc = sync_members(cm);
+        if (rc) return rc;
+        FS_HIP(hipSetDevice(c->device));
+        for (const Seg &s : segs) {
+            if (s.send) continue;
+            const fs_ctx *peer = cm->members[s.peer];
+            FS_HIP(hipMemcpy(seg_ptr(c, s), seg_ptr(peer, s), (size_t)(s.y1 - s.y0) * c->pitch * sizeof(float),
+                             hipMemcpyDeviceToDevice));
+        }
+        FS_HIP(hipDeviceSynchronize());
+        return FS_OK;
     }
-    FS_HIP(hipDeviceSynchronize());
-    return FS_OK;
+    if (cm->kind == 0) return FS_OK;
+    if (cm->kind == 2) {
+        int last = -1;
+        for (const Seg &s : segs) {
+            if (!s.send || s.peer == last) continue;
+            last = s.peer;
+            FS_HIP(hipStreamWaitEvent(c->xstream, cm->members[s.peer]->ev_copied[st.slot], 0));
+        }
+        FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_copied[st.slot], 0));
+        FS_HIP(hipEventRecord(c->ev_slot[st.slot], c->xstream));
+    }
+    c->pending[st.slot] = true;
+    return st.async ? FS_OK : join_slot(c, st.slot);
 }
 
-int comm_allreduce_max(fs_ctx *c)
+// max over ranks of the per-slab CFL bound; the value lands in pinned host memory behind ev_cfl
+int cfl_phase(fs_ctx *c, int phase)
 {
     fs_comm *cm = c->comm;
     if (!cm) { set_error("CFL reduction planned on a context without a communicator"); return FS_ERR_STATE; }
-    if (cm->kind == 1) {
-        FS_NCCL(g_rccl.AllReduce(c->cfl_dev, c->cfl_dev, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, c->stream));
-        FS_HIP(hipMemcpyAsync(c->cfl_host, c->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        FS_HIP(hipStreamSynchronize(c->stream));
-        c->cfl_max = *c->cfl_host;
+    if (phase == 0) {
+        if (cm->kind != 0) FS_HIP(hipEventRecord(c->ev_main, c->stream));
         return FS_OK;
     }
-    int rc = sync_members(cm);
-    if (rc) return rc;
-    float m = 0.0f;
-    for (fs_ctx *x : cm->members) {
-        float v = 0.0f;
-        FS_HIP(hipSetDevice(x->device));
-        FS_HIP(hipMemcpy(&v, x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost));
-        if (!(v <= m)) m = v;   // NaN propagates
+    if (phase != 1) return FS_OK;
+    if (cm->kind == 1) {
+        FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
+        FS_NCCL(g_rccl.AllReduce(c->cfl_dev, c->cfl_dev, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, c->xstream));
+        FS_HIP(hipMemcpyAsync(c->cfl_host, c->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
+        FS_HIP(hipEventRecord(c->ev_cfl, c->xstream));
+        return FS_OK;
     }
-    FS_HIP(hipSetDevice(c->device));
+    if (cm->kind == 0) {
+        int rc = sync_members(cm);
+        if (rc) return rc;
+        FS_HIP(hipSetDevice(c->device));
+    }
+    for (fs_ctx *x : cm->members) {
+        if (cm->kind == 2) {
+            FS_HIP(hipStreamWaitEvent(c->xstream, x->ev_main, 0));
+            FS_HIP(hipMemcpyAsync(&c->cfl_host[x->rank], x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
+        } else {
+            FS_HIP(hipMemcpy(&c->cfl_host[x->rank], x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost));
+        }
+    }
+    if (cm->kind == 2) FS_HIP(hipEventRecord(c->ev_cfl, c->xstream));
+    return FS_OK;
+}
+
+int wait_cfl(fs_ctx *c)
+{
+    fs_comm *cm = c->comm;
+    if (cm->kind != 0) FS_HIP(hipEventSynchronize(c->ev_cfl));
+    const int k = cm->kind == 1 ? 1 : cm->world;
+    float m = 0.0f;
+    for (int i = 0; i < k; ++i)
+        if (!(c->cfl_host[i] <= m)) m = c->cfl_host[i];   // NaN propagates
     c->cfl_max = m;
     return FS_OK;
 }
 
-int exec_step(fs_ctx *c, const Step &s)
+int exec_phase(fs_ctx *c, const Step &s, int phase)
 {
     switch (s.kind) {
-    case STEP_COMPUTE: return s.run();
-    case STEP_EXCHANGE: return comm_exchange(c, s.xf);
-    case STEP_CFL_REDUCE: return comm_allreduce_max(c);
+    case STEP_COMPUTE: return phase == 0 ? s.run() : FS_OK;
+    case STEP_EXCHANGE: return exchange_phase(c, s, phase);
+    case STEP_CFL_REDUCE: return cfl_phase(c, phase);
+    case STEP_JOIN: return phase == 0 ? join_slot(c, s.slot) : FS_OK;
     }
     return FS_ERR_STATE;
 }
 
 // bilinear taps lie within ceil(|v_y| dt) + 1 rows; +1 more because the dye is traced through the
 // ADVECTED velocity, whose fp32 mix() can exceed the old maximum by rounding only
-static int halo_from_cfl(fs_ctx *c, int *h)
+int halo_from_cfl(fs_ctx *c, int *h)
 {
     const double reach = (double)c->cfl_max * std::fabs((double)c->params.deltaTime);
     if (!(reach < 1.0e9)) {
@@ -507,23 +656,93 @@ static int halo_from_cfl(fs_ctx *c, int *h)
     return FS_OK;
 }
 
-int run_frame(fs_ctx *c)
+// the planned steps of all n slabs, in lock step (n = 1: a plain walk)
+int exec_all(fs_ctx **cs, int n)
 {
-    c->steps.clear();
-    plan_update_a(c);
-    int rc;
-    for (const Step &s : c->steps)
-        if ((rc = exec_step(c, s))) return rc;
-    int h = 0;
-    if (c->world > 1 && (rc = halo_from_cfl(c, &h))) return rc;
-    c->steps.clear();
-    plan_update_b(c, h);
-    for (const Step &s : c->steps)
-        if ((rc = exec_step(c, s))) return rc;
-    c->steps.clear();
-    c->stat_frames += 1;
+    const size_t count = cs[0]->steps.size();
+    for (int r = 1; r < n; ++r)
+        if (cs[r]->steps.size() != count) {
+            set_error("rank %d planned %zu steps, rank 0 %zu", r, cs[r]->steps.size(), count);
+            return ctx_fail(cs[r], FS_ERR_STATE);
+        }
+    for (size_t i = 0; i < count; ++i) {
+        const int phases = cs[0]->steps[i].kind == STEP_EXCHANGE || cs[0]->steps[i].kind == STEP_CFL_REDUCE ? 3 : 1;
+        for (int phase = 0; phase < phases; ++phase)
+            for (int r = 0; r < n; ++r) {
+                fs_ctx *c = cs[r];
+                if (n > 1) CTX(c);
+                TRY(c, exec_phase(c, c->steps[i], phase));
+            }
+    }
     return FS_OK;
 }
+
+struct Saved {
+    Field f[F_COUNT];
+};
+
+}  // namespace
+
+// One update() on n slabs (n = 1: this rank of an RCCL run, or a single GPU -- possibly under stream
+// capture, where nothing but kernel launches happens).
+int run_frames(fs_ctx **cs, int n)
+{
+    fs_ctx *c0 = cs[0];
+    const bool multi = c0->world > 1;
+    const fs_params &p = c0->params;
+    const bool ddn = p.diffusion > 0.0f && p.solverIterations > 0;
+    // speculate on the advection halo when the previous frame's is known and the advection can be redone
+    const bool spec = multi && c0->overlap && c0->last_true_halo >= 0 && !ddn;
+    int h = 0;
+    if (spec) h = std::min(c0->G, (c0->last_true_halo * 5 + 3) / 4 + 4);
+    for (int r = 0; r < n; ++r) {
+        cs[r]->steps.clear();
+        plan_update_a(cs[r], spec ? h : -1);
+    }
+    int rc = exec_all(cs, n);
+    if (rc) return rc;
+    int h_true = 0;
+    if (multi && !spec) {
+        for (int r = 0; r < n; ++r) {
+            TRY(cs[r], wait_cfl(cs[r]));
+            TRY(cs[r], halo_from_cfl(cs[r], &h_true));
+        }
+        h = h_true;
+    }
+    std::vector<Saved> saved(spec ? n : 0);
+    for (int r = 0; r < n; ++r) {
+        if (spec) std::copy(cs[r]->f, cs[r]->f + F_COUNT, saved[r].f);
+        cs[r]->steps.clear();
+        plan_update_b(cs[r], h);
+    }
+    if ((rc = exec_all(cs, n))) return rc;
+    if (spec) {
+        for (int r = 0; r < n; ++r) {
+            TRY(cs[r], wait_cfl(cs[r]));
+            TRY(cs[r], halo_from_cfl(cs[r], &h_true));
+        }
+        if (h_true > h) {
+            // The guess was too small: some backtraces read stale ghost rows.  Advection wrote only the
+            // ping-pong partners, so its inputs are intact: plan it again with the true depth.
+            for (int r = 0; r < n; ++r) {
+                fs_ctx *c = cs[r];
+                std::copy(saved[r].f, saved[r].f + F_COUNT, c->f);
+                c->stat_redo += 1;
+                c->steps.clear();
+                plan_update_b(c, h_true);
+            }
+            if ((rc = exec_all(cs, n))) return rc;
+        }
+    }
+    for (int r = 0; r < n; ++r) {
+        cs[r]->steps.clear();
+        cs[r]->stat_frames += 1;
+        if (multi) cs[r]->last_true_halo = h_true;
+    }
+    return FS_OK;
+}
+
+int run_frame(fs_ctx *c) { return run_frames(&c, 1); }
 
 static void append_plan(const fs_ctx *c, std::string &out)
 {
@@ -533,8 +752,11 @@ static void append_plan(const fs_ctx *c, std::string &out)
         if (s.kind == STEP_COMPUTE) {
             snprintf(line, sizeof(line), "%s %d %d %d\n", s.what, s.yb, s.ye, s.n);
             out += line;
+        } else if (s.kind == STEP_JOIN) {
+            out += s.what;
+            out += "\n";
         } else if (s.kind == STEP_EXCHANGE) {
-            out += "exchange";
+            out += s.what;
             for (const Xfer &x : s.xf) {
                 snprintf(line, sizeof(line), " %s:%d", names[x.field], x.depth);
                 out += line;
@@ -585,16 +807,20 @@ int fs_comm_create_rccl(int world, int rank, int device, const void *id128, fs_c
     return FS_OK;
 }
 
-int fs_comm_create_local(int world, fs_comm **out)
+static int create_local(int world, int kind, fs_comm **out)
 {
     if (!out || world < 1 || world > 1024) { set_error("fs_comm_create_local: bad arguments"); return FS_ERR_INVALID; }
     fs_comm *cm = new (std::nothrow) fs_comm();
     if (!cm) return FS_ERR_NOMEM;
-    cm->kind = 0; cm->world = world;
+    cm->kind = kind; cm->world = world;
     cm->members.assign(world, nullptr);
     *out = cm;
     return FS_OK;
 }
+
+int fs_comm_create_local(int world, fs_comm **out) { return create_local(world, 0, out); }
+
+int fs_comm_create_local_async(int world, fs_comm **out) { return create_local(world, 2, out); }
 
 int fs_comm_destroy(fs_comm *cm)
 {
@@ -655,9 +881,9 @@ int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, i
     if (comm->kind == 1) rank = comm->rank;
     if (rank < 0 || rank >= comm->world) { set_error("fs_create_slab: rank %d of %d", rank, comm->world); return FS_ERR_INVALID; }
     if (comm->kind == 1 && device != comm->device) { set_error("fs_create_slab: the communicator lives on device %d", comm->device); return FS_ERR_INVALID; }
-    if (comm->kind == 0 && comm->members[rank]) { set_error("fs_create_slab: rank %d already exists in this group", rank); return FS_ERR_INVALID; }
+    if (comm->kind != 1 && comm->members[rank]) { set_error("fs_create_slab: rank %d already exists in this group", rank); return FS_ERR_INVALID; }
     int rc = create_common(width, height, device, comm, comm->world, rank, ghost_rows, 0, false, out);
-    if (!rc && comm->kind == 0) comm->members[rank] = *out;
+    if (!rc && comm->kind != 1) comm->members[rank] = *out;
     return rc;
 }
 
@@ -668,10 +894,10 @@ int fs_slab_info(fs_ctx *c, int info[6])
     return FS_OK;
 }
 
-int fs_slab_stats(fs_ctx *c, long stats[3])
+int fs_slab_stats(fs_ctx *c, long stats[4])
 {
     if (!c || !stats) return FS_ERR_INVALID;
-    stats[0] = c->stat_exchanges; stats[1] = c->stat_rows; stats[2] = c->stat_frames;
+    stats[0] = c->stat_exchanges; stats[1] = c->stat_rows; stats[2] = c->stat_frames; stats[3] = c->stat_redo;
     return FS_OK;
 }
 
@@ -679,7 +905,7 @@ int fs_slab_stats(fs_ctx *c, long stats[3])
 // step i+1 of any, which is the ordering the exchanges of a real multi-process run enforce.
 int fs_group_step(fs_ctx **ctxs, int n)
 {
-    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->comm || ctxs[0]->comm->kind != 0 || ctxs[0]->comm->world != n) {
+    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->comm || ctxs[0]->comm->kind == 1 || ctxs[0]->comm->world != n) {
         set_error("fs_group_step: needs all %d contexts of one local group, in rank order", n);
         return FS_ERR_INVALID;
     }
@@ -688,38 +914,14 @@ int fs_group_step(fs_ctx **ctxs, int n)
             set_error("fs_group_step: context %d is not rank %d of the group", r, r);
             return FS_ERR_INVALID;
         }
-    for (int phase = 0; phase < 2; ++phase) {
-        for (int r = 0; r < n; ++r) {
-            fs_ctx *c = ctxs[r];
-            c->steps.clear();
-            if (phase == 0) {
-                plan_update_a(c);
-            } else {
-                int h = 0;
-                if (n > 1) TRY(c, halo_from_cfl(c, &h));
-                plan_update_b(c, h);
-            }
-            if (c->steps.size() != ctxs[0]->steps.size()) {
-                set_error("fs_group_step: rank %d planned %zu steps, rank 0 %zu", r, c->steps.size(), ctxs[0]->steps.size());
-                return ctx_fail(c, FS_ERR_STATE);
-            }
-        }
-        for (size_t i = 0; i < ctxs[0]->steps.size(); ++i)
-            for (int r = 0; r < n; ++r) {
-                fs_ctx *c = ctxs[r];
-                CTX(c);
-                TRY(c, exec_step(c, c->steps[i]));
-            }
-    }
-    for (int r = 0; r < n; ++r) { ctxs[r]->steps.clear(); ctxs[r]->stat_frames += 1; }
-    return FS_OK;
+    return run_frames(ctxs, n);
 }
 
 // Host-only: the frame plans of `frames` consecutive update() calls of one rank, as text (one step per
 // line: "<stage> <yb> <ye> <n>", "exchange <field>:<depth> ...", "cfl_allreduce"), with the advection
-// halo of frame f given by halos[f].  No GPU is touched.  Tests compare it with the Python planner.
-int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, const fs_params *p, int frames,
-                      const int *halos, char *buf, size_t cap)
+// halo of frame f given by halos[f] (and guessed exactly right by the frames that speculate).  No GPU is touched.  Tests compare it with the Python planner.
+int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, int overlap, const fs_params *p,
+                      int frames, const int *halos, char *buf, size_t cap)
 {
     if (!p || !buf || cap < 1 || frames < 0 || (frames > 0 && world > 1 && !halos)) { set_error("fs_slab_plan_dump: bad arguments"); return FS_ERR_INVALID; }
     fs_ctx *c = nullptr;
@@ -727,9 +929,13 @@ int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows
     if (rc) return rc;
     c->params = *p;
     std::string out;
+    c->overlap = overlap ? 1 : 0;
+    const bool ddn = p->diffusion > 0.0f && p->solverIterations > 0;
     for (int f = 0; f < frames; ++f) {
+        // a frame after the first speculates on its halo (here: exactly right) unless the dye diffuses
+        const bool spec = world > 1 && c->overlap && f > 0 && !ddn;
         c->steps.clear();
-        plan_update_a(c);
+        plan_update_a(c, spec ? halos[f] : -1);
         append_plan(c, out);
         c->steps.clear();
         plan_update_b(c, world > 1 ? halos[f] : 0);

@@ -18,7 +18,7 @@ FIELD_PLANES = {FIELD_VELOCITY: 2, FIELD_DENSITY: 3, FIELD_PRESSURE: 1, FIELD_DI
                 FIELD_VORTICITY: 1, FIELD_DISPLAY: 4}
 DISPLAY_NONE, DISPLAY_DENSITY, DISPLAY_VELOCITY, DISPLAY_SPEED, DISPLAY_VORTICITY, DISPLAY_PARTICLES_ONLY = -1, 0, 1, 2, 3, 4
 OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES, OPT_TILE_VARIANT, OPT_FUSE = 0, 1, 2, 3, 4
-OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE = 5, 6, 7, 8
+OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE, OPT_SLAB_OVERLAP = 5, 6, 7, 8, 9
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
  STAGE_FADE, STAGE_RENDER, STAGE_PRESSURE_CLEARED) = range(13)
@@ -76,6 +76,7 @@ SIGNATURES = {
     "fs_k_renderSpeed": (_i, [_G, _p, _p, _p, _sz, _f, _p]),
     "fs_k_particles_update": (_i, [_G, _p, _p, C.POINTER(ParticleParams), _l] + [_p] * 7 + [_p]),
     "fs_k_max_abs": (_i, [_G, _p, _p, _p]),
+    "fs_k_subtractGradient_cfl": (_i, [_G, _p, _p, _p, _p, _p]),
     "fs_create": (_i, [_i, _i, _i, _l, C.POINTER(_p)]),
     "fs_destroy": (_i, [_p]),
     "fs_reset": (_i, [_p]),
@@ -101,13 +102,14 @@ SIGNATURES = {
     "fs_comm_unique_id": (_i, [_p]),
     "fs_comm_create_rccl": (_i, [_i, _i, _i, _p, C.POINTER(_p)]),
     "fs_comm_create_local": (_i, [_i, C.POINTER(_p)]),
+    "fs_comm_create_local_async": (_i, [_i, C.POINTER(_p)]),
     "fs_comm_destroy": (_i, [_p]),
     "fs_comm_selftest": (_i, [_p, _i]),
     "fs_create_slab": (_i, [_i, _i, _i, _p, _i, _i, C.POINTER(_p)]),
     "fs_slab_info": (_i, [_p, C.POINTER(_i)]),
     "fs_slab_stats": (_i, [_p, C.POINTER(_l)]),
     "fs_group_step": (_i, [C.POINTER(_p), _i]),
-    "fs_slab_plan_dump": (_i, [_i, _i, _i, _i, _i, C.POINTER(Params), _i, C.POINTER(_i), C.c_char_p, _sz]),
+    "fs_slab_plan_dump": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(Params), _i, C.POINTER(_i), C.c_char_p, _sz]),
     "fs_last_error": (C.c_char_p, [_p]),
     "fs_version": (C.c_char_p, []),
     "fs_selftest_divide": (_i, [_f, C.POINTER(C.c_ulonglong)]),

@@ -28,21 +28,21 @@ def make_params(params, display=L.DISPLAY_NONE, brightness=0.06):
     return L.Params(v, d, dt, vs, fade, int(n), display, brightness)
 
 
-def plan_dump(W, H, world, rank, ghost, params, halos):
+def plan_dump(W, H, world, rank, ghost, params, halos, overlap=True):
     """Text of the frame plans of len(halos) consecutive update() calls (host only, no GPU)."""
     lib = L.load()
     p = make_params(params)
     hs = (C.c_int * max(1, len(halos)))(*halos)
     buf = C.create_string_buffer(1 << 20)
-    L.check(lib.fs_slab_plan_dump(W, H, world, rank, -1 if ghost is None else int(ghost), C.byref(p), len(halos), hs,
-                                  buf, len(buf)))
+    L.check(lib.fs_slab_plan_dump(W, H, world, rank, -1 if ghost is None else int(ghost), 1 if overlap else 0,
+                                  C.byref(p), len(halos), hs, buf, len(buf)))
     return buf.value.decode()
 
 
 class _Slab:
     """One fs_ctx created by fs_create_slab."""
 
-    def __init__(self, W, H, params, device, comm, rank, ghost, radius=5.0):
+    def __init__(self, W, H, params, device, comm, rank, ghost, radius=5.0, overlap=True):
         self.lib = L.load()
         self.W, self.H = int(W), int(H)
         self.radius = float(radius)
@@ -53,6 +53,7 @@ class _Slab:
         self.ctx = ctx
         p = make_params(params)
         L.check(self.lib.fs_set_params(self.ctx, C.byref(p)), self.ctx)
+        self.set_overlap(overlap)
         info = (C.c_int * 6)()
         L.check(self.lib.fs_slab_info(self.ctx, info))
         self.r0, self.r1, self.b0, self.b1, self.G = info[0], info[1], info[2], info[3], info[4]
@@ -61,6 +62,10 @@ class _Slab:
         if getattr(self, "ctx", None):
             self.lib.fs_destroy(self.ctx)
             self.ctx = None
+
+    def set_overlap(self, on):
+        """FS_OPT_SLAB_OVERLAP: hide the halo traffic behind the kernels (every rank must agree)."""
+        L.check(self.lib.fs_set_option(self.ctx, L.OPT_SLAB_OVERLAP, 1 if on else 0), self.ctx)
 
     def add_force(self, pos, force, color, dt=None):
         col = (C.c_float * 4)(float(color[0]), float(color[1]), float(color[2]), 0.0)
@@ -91,15 +96,15 @@ class _Slab:
 
     @property
     def stats(self):
-        st = (C.c_long * 3)()
+        st = (C.c_long * 4)()
         L.check(self.lib.fs_slab_stats(self.ctx, st))
-        return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2]}
+        return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2], "redo": st[3]}
 
 
 class RcclSlab(_Slab):
     """One rank's slab of a multi-process run: halos over RCCL send/recv inside the library."""
 
-    def __init__(self, W, H, params, device, rank, world, dist=None, ghost=None):
+    def __init__(self, W, H, params, device, rank, world, dist=None, ghost=None, overlap=True):
         lib = L.load()
         ident = np.zeros(L.COMM_ID_BYTES, np.uint8)
         if rank == 0:
@@ -118,7 +123,7 @@ class RcclSlab(_Slab):
                                         C.byref(comm)))
         self.comm = comm
         self.rank, self.world = rank, world
-        super().__init__(W, H, params, device, comm, rank, ghost)
+        super().__init__(W, H, params, device, comm, rank, ghost, overlap=overlap)
 
     def update(self):
         L.check(self.lib.fs_step(self.ctx), self.ctx)
@@ -140,16 +145,19 @@ class RcclSlab(_Slab):
 
 class LocalGroup:
     """K slabs of one W x H solver in this process, exchanging by device memcpy, stepped in lock step
-    (fs_group_step).  Exists to test the slab planner and kernels on a 1-GPU box."""
+    (fs_group_step).  Exists to test the slab planner and kernels on a 1-GPU box.  asynchronous=True:
+    the copies run on the slabs' exchange streams, ordered only by the events the RCCL path uses, so
+    the K slabs execute concurrently like K ranks."""
 
-    def __init__(self, W, H, params, world, device=0, ghost=None):
+    def __init__(self, W, H, params, world, device=0, ghost=None, asynchronous=False, overlap=True):
         self.lib = L.load()
         comm = C.c_void_p()
-        L.check(self.lib.fs_comm_create_local(int(world), C.byref(comm)))
+        make = self.lib.fs_comm_create_local_async if asynchronous else self.lib.fs_comm_create_local
+        L.check(make(int(world), C.byref(comm)))
         self.comm = comm
         self.world = world
         self.W, self.H = int(W), int(H)
-        self.slabs = [_Slab(W, H, params, device, comm, r, ghost) for r in range(world)]
+        self.slabs = [_Slab(W, H, params, device, comm, r, ghost, overlap=overlap) for r in range(world)]
         self._arr = (C.c_void_p * world)(*[s.ctx for s in self.slabs])
 
     def add_force(self, pos, force, color, dt=None):

@@ -15,6 +15,12 @@ contract is SURVEY.md 8(e):
     N diffuse sweeps -> divergence -> N pressure sweeps -> gradient), so a frame costs two exchange
     rounds (velocity at frame start; velocity + dye before advection) instead of one per sweep:
     the exchange is latency-bound, and redundant ghost-row compute is cheap.
+  * overlap=True (default, the native runtime's FS_OPT_SLAB_OVERLAP): the velocity advection also
+    computes the ghost rows the next frame's chain needs (so the frame-start round merges into the
+    pre-advection one), advection is split into interior rows and two rims, and the dye halo is
+    fetched at frame start from a guessed depth.  Here everything is synchronous -- this file is the
+    executable specification of the PLAN (which rows, which depths, in which order); the native
+    runtime runs the same plan with the transfers on a second stream.
   * The semi-Lagrangian backtrace is unbounded (Shaders:133-137), so the advection halo is sized per
     frame from the CFL bound: h = ceil(max|v_y| * dt) + 2 rows, max over all ranks (one 4-byte
     all-reduce).  If h exceeds the ghost capacity the source field is gathered whole (slow path).
@@ -104,6 +110,11 @@ class HipBackend:
         out.zero_()
         L.check(self.lib.fs_k_max_abs(C.byref(g), C.c_void_p(plane.data_ptr()), C.c_void_p(out.data_ptr()), self._s()))
 
+    def subtractGradient_cfl(self, g, p, vel, out):
+        out.zero_()
+        L.check(self.lib.fs_k_subtractGradient_cfl(C.byref(g), self._p(p), self._p(vel, 0), self._p(vel, 1),
+                                                   C.c_void_p(out.data_ptr()), self._s()))
+
 
 class Comm:
     """Thin wrapper of torch.distributed point-to-point + the 4-byte max all-reduce.
@@ -165,8 +176,9 @@ class SlabSolver:
     """One rank's slab of a W x H solver.  params = (viscosity, diffusion, deltaTime, vorticityStrength,
     fadeSpeed, solverIterations), the fields of fs_params that update() reads."""
 
-    def __init__(self, W, H, params, device=None, comm=None, backend=None, ghost=None, radius=5.0):
+    def __init__(self, W, H, params, device=None, comm=None, backend=None, ghost=None, radius=5.0, overlap=True):
         self.W, self.H = int(W), int(H)
+        self.overlap = bool(overlap)
         (self.viscosity, self.diffusion, self.deltaTime, self.vorticityStrength, self.fadeSpeed,
          self.solverIterations) = params
         self.radius = float(radius)
@@ -215,7 +227,10 @@ class SlabSolver:
         return t[:, y0 - self.b0:y1 - self.b0, :]
 
     # ---- halo exchange -------------------------------------------------------------------------
-    def _ensure(self, wants):
+    def _join(self, name):
+        """The native runtime waits here for the asynchronous exchange of `name`; nothing to do here."""
+
+    def _ensure(self, wants, tag="exchange"):
         """wants: list of (field, depth).  Refresh the ghost rows of every field whose valid depth is
         short, in ONE batched send/recv round.  Depths are capped at the ghost capacity."""
         if self.world == 1:
@@ -297,22 +312,33 @@ class SlabSolver:
         self.be.addForces(g, self.f["vel"], self.f["dye"], [float(x) for x in pos], [float(x) for x in force],
                           [float(x) for x in color], self.radius, float(self.deltaTime if dt is None else dt))
 
-    def update(self):
-        """FluidSolver.update(), FluidSolver.swift:477-591, on this slab."""
+    def _chain_needs(self):
+        """Ghost depths the velocity chain needs, backwards from subtractGradient on the owned rows:
+        p(1) <- N sweeps <- div(N) <- vel(N+1) <- N diffuse sweeps <- vel(2N+1) <- applyVorticity
+        <- vort(2N+2) <- vel(2N+3)"""
+        N = int(self.solverIterations)
+        need_p = 1
+        need_div = need_p + max(N - 1, 0)
+        need_v2 = need_div + 1
+        need_v1 = need_v2 + (N if self.viscosity > 0 else 0)
+        need_v0 = need_v1 + (2 if self.vorticityStrength > 0 else 0)
+        return need_p, need_div, need_v2, need_v1, need_v0
+
+    def update(self, h_spec=None):
+        """FluidSolver.update(), FluidSolver.swift:477-591, on this slab.  h_spec: the advection halo the
+        frame is expected to need (the native runtime guesses it from the previous frame)."""
         N = int(self.solverIterations)
         dt = float(self.deltaTime)
         vort_on, visc_on, ddiff_on = self.vorticityStrength > 0, self.viscosity > 0, self.diffusion > 0
         multi = self.world > 1
         V = self.valid
         eff = lambda name: min(V[name], self.G)   # noqa: E731  usable depth: valid AND present in the buffer
-        # ghost depths the velocity chain needs, backwards from subtractGradient on the owned rows:
-        # p(1) <- N sweeps <- div(N) <- vel(N+1) <- N diffuse sweeps <- vel(2N+1) <- applyVorticity
-        # <- vort(2N+2) <- vel(2N+3)
-        need_p = 1
-        need_div = need_p + max(N - 1, 0)
-        need_v2 = need_div + 1
-        need_v1 = need_v2 + (N if visc_on else 0)
-        need_v0 = need_v1 + (2 if vort_on else 0)
+        need_p, need_div, need_v2, need_v1, need_v0 = self._chain_needs()
+        ddn = N if (ddiff_on and N > 0) else 0
+        if not (multi and self.overlap and ddn == 0):
+            h_spec = None
+        if h_spec is not None:
+            self._ensure([("dye", h_spec)], "exchange_async")                  # under the whole stencil chain
 
         if vort_on:                                                            # :486-502
             self._need("vel", need_v0)
@@ -338,52 +364,80 @@ class SlabSolver:
         else:
             self.be.clear(self.grid(self.G), self.f["p"])
         self._need("p", 1)
-        self.be.subtractGradient(self.grid(0), self.f["p"], self.f["vel"])     # :544-547
-        if multi:
-            V["vel"] = 0
         # ---- advection: halo from the CFL bound of the backtrace ----
-        ddn = N if (ddiff_on and N > 0) else 0
         h = 0
-        if multi:
-            self.be.max_abs(self.grid(0), self.f["vel"][1], self.cfl)
+        if not multi:
+            self.be.subtractGradient(self.grid(0), self.f["p"], self.f["vel"])     # :544-547
+        else:
+            # ... with max |v_y| of the owned rows in the same pass, then max over ranks
+            self.be.subtractGradient_cfl(self.grid(0), self.f["p"], self.f["vel"], self.cfl)
+            V["vel"] = 0
             self.comm.allreduce_max(self.cfl)
             # bilinear taps lie within ceil(|v_y| dt) + 1 rows; +1 more because the dye is traced through
             # the ADVECTED velocity, whose fp32 mix() can exceed the old maximum by rounding only
             h = int(math.ceil(float(self.cfl.item()) * abs(dt))) + 2
             self.last_halo = h
+            if h_spec is not None and h_spec >= h:
+                h = h_spec                                                     # the guess holds: plan with it
         if multi and h > self.G:                                               # slow path: gather whole fields
             self._advect_gathered("vel")
             if ddn:
                 self._need("dye", ddn)
                 self._sweeps("diffuse", "dye", N, 0)
             self._advect_gathered("dye")
+            self.be.fade(self.grid(0), self.f["dye"], float(self.fadeSpeed))   # :587-591
+            V["dye"] = 0
+            return
+        fused = hasattr(self.be, "advect_fade")
+        # overlap: the advected velocity is also computed on the ghost rows the next frame's chain
+        # consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
+        adv = max(0, min(need_v0, self.G - h)) if (multi and self.overlap) else 0
+        split = multi and self.overlap and ddn == 0 and self.H // self.world > 2 * h + 8
+        if split:
+            self._ensure([("vel", h + adv), ("dye", h)], "exchange_async")
+            i0 = self.r0 + (h if self.r0 > 0 else 0)
+            i1 = self.r1 - (h if self.r1 < self.H else 0)
+            old, new = self.f["vel"], self.f["vel_t"]
+            # interior rows: no tap of their backtrace leaves the owned rows    :550-558, :577-591
+            self._advect_rows("vel", old, i0, i1, False)
+            self._advect_rows("dye", new, i0, i1, fused)
+            self._join("vel")
+            self._advect_rows("vel", old, self.r0 - adv, i0, False)
+            self._advect_rows("vel", old, i1, self.r1 + adv, False)
+            self.f["vel"], self.f["vel_t"] = new, old                          # :558
+            V["vel"] = adv
+            self._join("dye")
+            self._advect_rows("dye", new, self.r0, i0, fused)
+            self._advect_rows("dye", new, i1, self.r1, fused)
+            self.f["dye"], self.f["dye_t"] = self.f["dye_t"], self.f["dye"]    # :584
         else:
             if multi:
-                self._ensure([("vel", h), ("dye", h + ddn)])                   # one batched round
-            self._advect_local("vel")                                          # :550-558
+                self._ensure([("vel", h + adv), ("dye", h + ddn)])             # one batched round
+                self._join("dye")
+            self._advect_rows("vel", self.f["vel"], self.r0 - adv, self.r1 + adv, False)   # :550-558
+            self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
+            if multi:
+                V["vel"] = adv
             if ddn:
                 self._sweeps("diffuse", "dye", N, h)                           # :562-574
                 self._need("dye", h)
-            if hasattr(self.be, "advect_fade"):                                # :577-591 in one pass
-                self._advect_local("dye", fade=True)
-                if multi:
-                    V["dye"] = 0
-                return
-            self._advect_local("dye")                                          # :577-584
-        self.be.fade(self.grid(0), self.f["dye"], float(self.fadeSpeed))       # :587-591
+            self._advect_rows("dye", self.f["vel"], self.r0, self.r1, fused)   # :577-584 (+ :587-591 when fused)
+            self.f["dye"], self.f["dye_t"] = self.f["dye_t"], self.f["dye"]
+        if not fused:
+            self.be.fade(self.grid(0), self.f["dye"], float(self.fadeSpeed))   # :587-591
         if multi:
             V["dye"] = 0
 
-    def _advect_local(self, name, fade=False):
+    def _advect_rows(self, name, vel, yb, ye, fade):
+        """advect field `name` through `vel` on rows [yb, ye) (clipped to the buffer), into its partner."""
+        yb = max(yb, self.b0)
+        ye = max(yb, min(ye, self.b1))
+        g = L.Grid(self.W, self.H, self.pitch, self.b0, self.b1 - self.b0, yb, ye)
         src, dst = self.f[name], self.f[name + "_t"]
         if fade:
-            self.be.advect_fade(self.grid(0), self.f["vel"], src, dst, float(self.deltaTime), float(self.fadeSpeed),
-                                self.err)
+            self.be.advect_fade(g, vel, src, dst, float(self.deltaTime), float(self.fadeSpeed), self.err)
         else:
-            self.be.advect(self.grid(0), self.f["vel"], src, dst, float(self.deltaTime), self.err)
-        self.f[name], self.f[name + "_t"] = dst, src
-        if self.world > 1:
-            self.valid[name] = 0
+            self.be.advect(g, vel, src, dst, float(self.deltaTime), self.err)
 
     def _gather_full(self, name):
         """Slow path: every rank receives the whole field (row blocks broadcast by their owners)."""

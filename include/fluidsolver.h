@@ -175,6 +175,12 @@ int fs_k_particles_update(const fs_grid *g, const float *u, const float *v,
  * Used to size the advection halo of a row slab: ceil(max|v_y| * dt) + 1 rows. */
 int fs_k_max_abs(const fs_grid *g, const float *plane, float *out_dev, void *stream);
 
+/* subtractGradient (Shaders:225-245) and, in the same pass over the velocity, fs_k_max_abs of the
+ * new v plane over rows [yb,ye) into *cfl_dev (device float; must hold a lower bound, normally 0.0f,
+ * beforehand).  Velocity bits equal fs_k_subtractGradient's, the maximum equals fs_k_max_abs's.  The
+ * CFL part has no counterpart in the reference; the slab runtime uses it to save a pass. */
+int fs_k_subtractGradient_cfl(const fs_grid *g, const float *p, float *u, float *v, float *cfl_dev, void *stream);
+
 /* -------------------------------------------------------------------------
  * Layer 2: solver context (mirrors class FluidSolver, Solver:240-632, and the
  * update half of class ParticleSystem, Part:242-304).
@@ -209,6 +215,9 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */
+       FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
+                                     behind the kernels (second stream, split advection, speculated halo
+                                     depth); 0 = exchange, wait, compute */
        FS_OPT_TILE_VARIANT = 3    /* Jacobi tile shape (rows per lane x waves): 0 = 8x8, 1 = 16x8,
                                      2 = 8x16, 3 = 16x4, 4 = 4x16 (default), 5 = 12x8 */ };
 
@@ -266,8 +275,9 @@ long fs_particles_count(fs_ctx *ctx);
  * the contract is SURVEY.md 8(e).  GPU g owns rows [g*H/k, (g+1)*H/k) and all columns; halo rows
  * move with ncclSend/ncclRecv between slab neighbours over xGMI, two batched rounds per frame
  * (deep ghost zones, recomputed redundantly), plus one 4-byte all-reduce(max) that sizes the
- * advection halo from the CFL bound of the backtrace.  Every stage is the same kernel as on one
- * GPU, so k slabs equal one GPU bit for bit.
+ * advection halo from the CFL bound of the backtrace.  The transfers run on a second stream under
+ * the kernels (FS_OPT_SLAB_OVERLAP).  Every stage is the same kernel as on one GPU, so k slabs
+ * equal one GPU bit for bit.
  *
  * One process per GPU:
  *     rank 0: fs_comm_unique_id(id); broadcast id to all ranks by any means (torch.distributed, MPI, a file)
@@ -285,6 +295,9 @@ int fs_comm_create_rccl(int world, int rank, int device, const void *id128, fs_c
 /* In-process group: all `world` slabs live in this process (on one GPU or several) and exchange by
  * device memcpy.  It exists to test the slab logic on a 1-GPU box; step it with fs_group_step. */
 int fs_comm_create_local(int world, fs_comm **out);
+/* The same, but the copies are asynchronous on each slab's exchange stream and ordered only by the
+ * events the RCCL path uses: the K slabs run concurrently on the GPU, as K ranks would. */
+int fs_comm_create_local_async(int world, fs_comm **out);
 int fs_comm_destroy(fs_comm *comm);   /* after the contexts that use it */
 /* Round trip through an RCCL communicator (collective: every rank calls it): `count` floats to the
  * next rank / from the previous one in one send/recv group, and a 1-float all-reduce(max). */
@@ -295,12 +308,13 @@ int fs_comm_selftest(fs_comm *comm, int count);
  * are legal (rows then come from several ranks).  Tracers and fs_stage are single-GPU only. */
 int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out);
 int fs_slab_info(fs_ctx *ctx, int info[6]);   /* r0, r1 (owned rows), b0, b1 (buffered rows), ghost capacity, last advection halo */
-int fs_slab_stats(fs_ctx *ctx, long stats[3]); /* exchange rounds, halo rows sent, frames */
+int fs_slab_stats(fs_ctx *ctx, long stats[4]); /* exchange rounds, halo rows sent, frames, advection re-plans (halo guessed too small) */
 int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
 /* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
- * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f. */
-int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, const fs_params *p, int frames,
-                      const int *halos, char *buf, size_t cap);
+ * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f;
+ * overlap = the FS_OPT_SLAB_OVERLAP setting to plan for. */
+int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, int overlap, const fs_params *p,
+                      int frames, const int *halos, char *buf, size_t cap);
 
 const char *fs_last_error(fs_ctx *ctx); /* ctx may be NULL: last error of the calling thread */
 const char *fs_version(void);

@@ -111,5 +111,9 @@ class OracleBackend:
             self.o.fadeDensity(self._og(g), d[pl], rate)
         self._back(dye, d, W)
 
+    def subtractGradient_cfl(self, g, p, vel, out):
+        self.subtractGradient(g, p, vel)
+        self.max_abs(g, vel[1], out)
+
     def max_abs(self, g, plane, out):
         out[0] = float(plane[g.yb - g.y0:g.ye - g.y0, :g.width].abs().max()) if g.ye > g.yb else 0.0

@@ -64,6 +64,24 @@ def test_subtract_gradient_and_apply_vorticity(lib, oracle, W, H):
     ok(lib.fs_k_subtractGradient(C.byref(g), ptr(dp), ptr(dv, 0), ptr(dv, 1), stream()))
     sync()
     assert np.array_equal(host_planes(dv, W), e)
+    # the same pass with the CFL reduction folded in, on a row range (the slab runtime's call): same
+    # velocity bits on the computed rows, untouched elsewhere, max |v| of exactly those rows
+    import torch
+    yb, ye = (1, H - 1) if H > 4 else (0, H)
+    e2 = vel.copy()
+    from oracle_binding import Grid as OGrid
+    oracle.subtractGradient(OGrid(W, H, 0, H, yb, ye), p, e2[0], e2[1])
+    dv2 = dev_planes(vel)
+    cfl = torch.zeros(1, dtype=torch.float32, device="cuda")
+    g2 = grid(W, H, yb=yb, ye=ye)
+    ok(lib.fs_k_subtractGradient_cfl(C.byref(g2), ptr(dp), ptr(dv2, 0), ptr(dv2, 1), C.c_void_p(cfl.data_ptr()), stream()))
+    sync()
+    assert np.array_equal(host_planes(dv2, W), e2)
+    assert float(cfl.item()) == float(np.abs(e2[1][yb:ye]).max())
+    ref = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ok(lib.fs_k_max_abs(C.byref(g2), ptr(dv2, 1), C.c_void_p(ref.data_ptr()), stream()))
+    sync()
+    assert float(ref.item()) == float(cfl.item())
     e = vel.copy()
     oracle.applyVorticity(full_grid(W, H), w, e[0], e[1], 10.0, 0.5)
     dv, dw = dev_planes(vel), dev_planes(w)

@@ -25,11 +25,17 @@ CASES = {
 }
 
 
-def _run_group(case, world):
+# transport x plan: blocking copies / asynchronous copies ordered by the RCCL path's events; halo
+# traffic exposed (exchange, wait, compute) / hidden (second stream, split advection, guessed halo)
+MODES = {"blocking-plain": (False, False), "blocking-overlap": (False, True), "async-plain": (True, False),
+         "async-overlap": (True, True)}
+
+
+def _run_group(case, world, asynchronous=False, overlap=True):
     from fluidsolver_amd.native_slabs import LocalGroup
     from fluidsolver_amd.script import splat
     W, H, params, ghost, frames, fscale = case
-    g = LocalGroup(W, H, params, world, device=0, ghost=ghost)
+    g = LocalGroup(W, H, params, world, device=0, ghost=ghost, asynchronous=asynchronous, overlap=overlap)
     try:
         halos = []
         for f in range(frames):
@@ -44,13 +50,19 @@ def _run_group(case, world):
         g.close()
 
 
+_REF = {}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_local_group_equals_oracle(oracle_omp, world, name):
+def test_local_group_equals_oracle(oracle_omp, world, name, mode):
     import test_slabs as T
     case = CASES[name]
-    vel, dye, prs, halos, stats = _run_group(case, world)
-    rvel, rdye, rprs = T._reference(case)
+    vel, dye, prs, halos, stats = _run_group(case, world, *MODES[mode])
+    if name not in _REF:
+        _REF[name] = T._reference(case)
+    rvel, rdye, rprs = _REF[name]
     assert np.array_equal(vel, rvel), (name, "vel")
     assert np.array_equal(dye, rdye), (name, "dye")
     assert np.array_equal(prs, rprs), (name, "p")
@@ -60,32 +72,72 @@ def test_local_group_equals_oracle(oracle_omp, world, name):
     if name == "config2_physics" and world <= 3:
         # two exchange rounds per frame (one in the first frame, whose all-zero fields need none at its start)
         assert all(s["exchanges"] == 2 * case[4] - 1 for s in stats), stats
+    if not MODES[mode][1]:
+        assert all(s["redo"] == 0 for s in stats)
 
 
-def test_local_group_equals_single_gpu_context_at_size():
-    """4 slabs of a 1536 x 1024 grid, N = 40, against fs_step on the whole grid (no oracle: too slow)."""
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_local_group_equals_single_gpu_context_at_size(mode):
+    """4 slabs of a 1536 x 1024 grid, N = 40, full-strength scripted splats (advection halo of tens of
+    rows, changing from frame to frame) against fs_step on the whole grid (no oracle: too slow)."""
     from fluidsolver_amd import FluidSolver, lib as L
     from fluidsolver_amd.native_slabs import LocalGroup
     from fluidsolver_amd.script import splat
     W, H, params = 1536, 1024, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
-    g = LocalGroup(W, H, params, 4, device=0)
+    asynchronous, overlap = MODES[mode]
+    g = LocalGroup(W, H, params, 4, device=0, asynchronous=asynchronous, overlap=overlap)
     s = FluidSolver(W, H)
     (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
     s.displayMode = None
     try:
-        for f in range(6):
+        halos = []
+        for f in range(12):
             for ptr in range(4):
                 pos, force, col = splat(W, H, 7 * f + 1, ptr, 4)
                 g.add_force(pos, force, col)
                 s.applyForce(pos, force, col)
             g.update()
             s.update()
+            halos.append(g.slabs[0].last_halo)
         g.sync()
         s.sync()
+        assert max(halos) > 8, halos
         assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
         assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
         assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
         assert np.abs(g.field("vel")).max() > 0
+    finally:
+        g.close()
+        s.close()
+
+
+def test_wrong_halo_guess_is_replanned():
+    """Overlap mode guesses the advection halo from the previous frame.  A splat 40x stronger than the
+    last one makes the guess too small: the advection must be planned again with the true depth (counted
+    in the stats) and the fields must still equal the single-GPU run bit for bit."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params = 512, 768, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 10)
+    g = LocalGroup(W, H, params, 3, device=0, asynchronous=True, overlap=True)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        halos = []
+        for f, strength in enumerate([5.0, 5.0, 200.0, 200.0, 5.0, 900.0, 1.0]):
+            pos, force, col = (200.0 + 30 * f, 250.0 + 3 * f), (0.3 * strength, strength), (50.0, 20.0, 5.0)
+            g.add_force(pos, force, col)
+            s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+            halos.append(g.slabs[0].last_halo)
+        g.sync()
+        s.sync()
+        redo = [sl.stats["redo"] for sl in g.slabs]
+        assert redo[0] >= 2 and len(set(redo)) == 1, (redo, halos)
+        assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
+        assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
     finally:
         g.close()
         s.close()
@@ -99,7 +151,7 @@ def test_written_fields_invalidate_ghosts():
     rng = np.random.default_rng(7)
     vel = rng.uniform(-2, 2, (2, H, W)).astype(F)
     dye = rng.uniform(0, 1, (3, H, W)).astype(F)
-    g = LocalGroup(W, H, params, world, device=0)
+    g = LocalGroup(W, H, params, world, device=0, asynchronous=True)
     s = FluidSolver(W, H)
     (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
     s.displayMode = None

@@ -54,8 +54,8 @@ class _Recorder:
         depth = L.load().fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE if op else L.OPT_BLOCK_DEPTH_PRESSURE)
         return (n + depth - 1) // depth
 
-    def max_abs(self, g, plane, out):
-        self._rec("max_abs", g)
+    def subtractGradient_cfl(self, g, p, vel, out):
+        self._rec("subtractGradient_cfl", g)
         out.fill_(self.next_cfl)
 
 
@@ -68,26 +68,29 @@ class _Comm:
 
 
 class _PlanOnly(SlabSolver):
-    def _ensure(self, wants):
+    def _ensure(self, wants, tag="exchange"):
         if self.world == 1:
             return
         todo = [(n, min(d, self.G)) for n, d in wants if self.valid[n] < min(d, self.G)]
         if todo:
-            self.comm.log.append("exchange " + " ".join("%s:%d" % t for t in todo))
+            self.comm.log.append(tag + " " + " ".join("%s:%d" % t for t in todo))
             for n, d in todo:
                 self.valid[n] = d
 
+    def _join(self, name):
+        self.comm.log.append("join " + name)
 
-def python_plan(W, H, world, rank, ghost, params, halos):
+
+def python_plan(W, H, world, rank, ghost, params, halos, overlap=True):
     log = []
     be = _Recorder(log)
     s = _PlanOnly(W, H, params, device="cpu", comm=_Comm(rank, world, log) if world > 1 else None, backend=be,
-                  ghost=ghost)
+                  ghost=ghost, overlap=overlap)
     s.comm = _Comm(rank, world, log) if world > 1 else None
     dt = abs(params[2])
-    for h in halos:
+    for f, h in enumerate(halos):
         be.next_cfl = (h - 2.5) / dt if world > 1 else 0.0   # ceil(cfl * dt) + 2 == h
-        s.update()
+        s.update(h_spec=h if f > 0 else None)                # frames after the first guess their halo (here: right)
         if world > 1:
             assert s.last_halo == h
     return "\n".join(log) + "\n"
@@ -106,15 +109,16 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_native_plan_equals_python_plan(name, world):
+def test_native_plan_equals_python_plan(name, world, overlap):
     W, H, params, ghost, halos = CASES[name]
     if H // world < 4:
         pytest.skip("slabs too thin")
     for rank in sorted({0, world // 2, world - 1}):
-        native = NS.plan_dump(W, H, world, rank, ghost, params, halos)
-        python = python_plan(W, H, world, rank, ghost, params, halos)
+        native = NS.plan_dump(W, H, world, rank, ghost, params, halos, overlap)
+        python = python_plan(W, H, world, rank, ghost, params, halos, overlap)
         assert native == python, "rank %d of %d\n--- native ---\n%s--- python ---\n%s" % (rank, world, native, python)
         assert "subtractGradient" in native
         if world > 1:
@@ -122,12 +126,37 @@ def test_native_plan_equals_python_plan(name, world):
 
 
 def test_deep_halo_plan_has_two_exchange_rounds_per_frame():
-    """Config 4 on 8 GPUs: after the first frame (all-zero fields need no exchange) every frame costs
-    exactly two exchange rounds -- velocity at frame start, velocity + dye before advection."""
+    """Config 4 on 8 GPUs without overlap: after the first frame (all-zero fields need no exchange) every
+    frame costs exactly two exchange rounds -- velocity at frame start, velocity + dye before advection."""
     W, H, params, ghost, _ = CASES["config2_8gpu"]
-    text = NS.plan_dump(W, H, 8, 3, None, params, [5, 5, 5])
+    text = NS.plan_dump(W, H, 8, 3, None, params, [5, 5, 5], overlap=False)
     frames = text.split("cfl_allreduce\n")
     assert len(frames) == 4
     assert text.count("exchange") == 1 + 2 + 2      # frame 0: only the pre-advection round
     assert "exchange vel:83\n" in text              # 2N + 3 rows of velocity in one round
     assert "exchange vel:5 dye:5\n" in text
+    assert "async" not in text and "join" not in text.replace("join dye\n", "")
+
+
+def test_overlap_plan_hides_both_rounds():
+    """Config 4 on 8 GPUs with overlap: two asynchronous rounds per frame and no blocking one -- the dye
+    halo at frame start (joined before the dye rims), velocity h + 2N+3 rows after the projection (joined
+    before the velocity rims); the interior rows are advected in between; the next frame starts without
+    an exchange because the advected velocity was also computed on 2N+3 ghost rows."""
+    W, H, params, ghost, _ = CASES["config2_8gpu"]
+    text = NS.plan_dump(W, H, 8, 3, None, params, [5, 7, 7])
+    lines = text.split("\n")
+    assert "exchange vel:83" not in lines
+    frame2 = text.split("cfl_allreduce\n")[2]                  # advection of frame 1 + chain of frame 2
+    f = frame2.split("\n")
+    r0, r1 = 3 * 2048, 4 * 2048
+    assert f[0] == "exchange_async vel:90"                      # 7 + 83
+    assert f[1] == "advect %d %d 2" % (r0 + 7, r1 - 7)
+    assert f[2] == "advect_fade %d %d 3" % (r0 + 7, r1 - 7)
+    assert f[3] == "join vel"
+    assert f[4] == "advect %d %d 2" % (r0 - 83, r0 + 7) and f[5] == "advect %d %d 2" % (r1 - 7, r1 + 83)
+    assert f[6] == "join dye"
+    assert f[7] == "advect_fade %d %d 3" % (r0, r0 + 7) and f[8] == "advect_fade %d %d 3" % (r1 - 7, r1)
+    assert f[9] == "exchange_async dye:7"                       # frame 2 begins: dye halo under the chain
+    assert f[10].startswith("vorticity %d %d" % (r0 - 82, r1 + 82))
+    assert not any(x.startswith("exchange ") for x in f)
