@@ -234,14 +234,35 @@ def main():
         sync_all = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
         total_cells = W * H
         parallelism = "%d row slabs (RCCL send/recv halo exchange over xGMI)" % world
+        # Untimed A/B of the two frame plans on this machine's links (FS_OPT_SLAB_OVERLAP: halo traffic
+        # hidden behind the kernels / exchange-wait-compute); the timed run uses the faster one.  Same
+        # results either way (bit-identical fields), every rank takes the same decision (max over ranks).
+        forced = os.environ.get("FS_BENCH_SLAB_OVERLAP")
+        ab, f0 = {}, 0
+        for mode in ((1, 0) if forced is None else (int(forced),)):
+            s.set_overlap(mode)
+            for f in range(f0, f0 + 4):
+                step(f)
+            sync_all(); barrier()
+            t0 = time.perf_counter()
+            for f in range(f0 + 4, f0 + 12):
+                step(f)
+            sync_all(); barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / 8.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ab[mode] = float(t.item()) * 1e3
+            f0 += 12
+        overlap = min(ab, key=ab.get)
+        s.set_overlap(overlap)
 
-    for f in range(args.warmup):
+    f0 = f0 if slabs else 0
+    for f in range(f0, f0 + args.warmup):
         step(f)
     sync_all()
     barrier()
     sync_all()
     t0 = time.perf_counter()
-    for f in range(args.warmup, args.warmup + args.steps):
+    for f in range(f0 + args.warmup, f0 + args.warmup + args.steps):
         step(f)
     sync_all()
     barrier()
@@ -295,7 +316,9 @@ def main():
         st = s.stats
         out["slab"] = {"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
-                       "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"]))}
+                       "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
+                       "overlap": bool(overlap), "advection_replans": st["redo"],
+                       "untimed_ab_ms_per_frame": {"overlap": ab.get(1), "plain": ab.get(0)}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if slabs:

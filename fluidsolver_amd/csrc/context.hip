@@ -309,7 +309,7 @@ int fs_reset(fs_ctx *c)
     }
     TRYHIP(c, hipMemsetAsync(c->display, 0, 4 * pb, c->stream));
     TRYHIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
-    c->last_true_halo = -1;
+    for (int &h : c->halo_hist) h = -1;
     return FS_OK;
 }
 

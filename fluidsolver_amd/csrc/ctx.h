@@ -92,7 +92,7 @@ struct fs_ctx {
     bool pending[fs::SLOT_COUNT] = {false, false, false};
     hipEvent_t ev_cfl = nullptr;        // CFL value has landed in cfl_host
     int overlap = 1;                    // FS_OPT_SLAB_OVERLAP: speculative halo + split advection
-    int last_true_halo = -1;            // advection halo the previous frame really needed (-1: unknown)
+    int halo_hist[4] = {-1, -1, -1, -1};   // advection halos the last frames really needed (-1: unknown), newest first
     fs_params params{};
     int use_graph = 1;
     int with_particles = 0;

@@ -23,7 +23,7 @@
 //     kernel, same inputs as the owner => same bits), so the frame-start exchange disappears into the
 //     pre-advection one (depth h + 2N+3); (3) advection is split into interior rows, whose backtrace
 //     cannot leave the owned rows, and two rims: the interior of the velocity and of the dye run while
-//     the halo is in flight; (4) the halo depth is SPECULATED from the previous frame (1.25 h + 4), so
+//     the halo is in flight; (4) the halo depth is SPECULATED from the last four frames (1.25 max + 4), so
 //     the dye halo is fetched at frame start, under the whole stencil chain, and the host never waits
 //     for the CFL value before enqueueing; advection writes to the ping-pong partner, so when the
 //     all-reduced bound turns out larger than the guess the advection part of the frame is simply
@@ -692,9 +692,12 @@ int run_frames(fs_ctx **cs, int n)
     const fs_params &p = c0->params;
     const bool ddn = p.diffusion > 0.0f && p.solverIterations > 0;
     // speculate on the advection halo when the previous frame's is known and the advection can be redone
-    const bool spec = multi && c0->overlap && c0->last_true_halo >= 0 && !ddn;
+    // (the guess: the bound is set by the newest splat's jet and jumps by 2x from frame to frame --
+    // profiles/r01_probe_halo_series.log -- so it is the envelope of the last four frames, + 25 % + 4 rows)
+    const int envelope = *std::max_element(c0->halo_hist, c0->halo_hist + 4);
+    const bool spec = multi && c0->overlap && c0->halo_hist[0] >= 0 && !ddn;
     int h = 0;
-    if (spec) h = std::min(c0->G, (c0->last_true_halo * 5 + 3) / 4 + 4);
+    if (spec) h = std::min(c0->G, (envelope * 5 + 3) / 4 + 4);
     for (int r = 0; r < n; ++r) {
         cs[r]->steps.clear();
         plan_update_a(cs[r], spec ? h : -1);
@@ -737,7 +740,10 @@ int run_frames(fs_ctx **cs, int n)
     for (int r = 0; r < n; ++r) {
         cs[r]->steps.clear();
         cs[r]->stat_frames += 1;
-        if (multi) cs[r]->last_true_halo = h_true;
+        if (multi) {
+            int *hist = cs[r]->halo_hist;
+            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = h_true;
+        }
     }
     return FS_OK;
 }
