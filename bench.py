@@ -190,6 +190,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FS_BENCH_DEVICE"):   # test hook: rehearse N ranks on one GPU (with tests/mock_rccl)
+        local_rank = int(os.environ["FS_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "

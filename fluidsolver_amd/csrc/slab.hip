@@ -404,12 +404,16 @@ int load_rccl()
 {
     if (g_rccl.handle) return FS_OK;
     void *h = nullptr;
-    // a copy already in the process (e.g. the one PyTorch ships) wins, so one RCCL serves the process
+    // FS_RCCL_LIBRARY wins; else a copy already in the process (e.g. the one PyTorch ships), so that one
+    // RCCL serves the process; else the default search path
+    const char *env = getenv("FS_RCCL_LIBRARY");
+    if (env && *env) {
+        h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("cannot load FS_RCCL_LIBRARY=%s (%s)", env, dlerror()); return FS_ERR_STATE; }
+    }
     const char *loaded[] = {"librccl.so.1", "librccl.so"};
     for (const char *n : loaded)
         if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    const char *env = getenv("FS_RCCL_LIBRARY");
-    if (!h && env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
     const char *paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : paths)
         if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);

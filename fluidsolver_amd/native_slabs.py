@@ -109,7 +109,9 @@ class RcclSlab(_Slab):
         ident = np.zeros(L.COMM_ID_BYTES, np.uint8)
         if rank == 0:
             L.check(lib.fs_comm_unique_id(ident.ctypes.data_as(C.c_void_p)))
-        if world > 1:
+        if world > 1 and hasattr(dist, "broadcast_id"):
+            ident = dist.broadcast_id(ident, rank)      # any other control plane (a file, MPI, ...)
+        elif world > 1:
             if dist is None:
                 raise ValueError("world > 1 needs an initialised torch.distributed group to hand out the RCCL id")
             import torch

@@ -285,7 +285,7 @@ long fs_particles_count(fs_ctx *ctx);
  *             fs_create_slab(W, H, device, comm, rank, -1, &ctx);
  *             per frame: fs_add_force(ctx, ...) with GLOBAL coordinates on EVERY rank; fs_step(ctx);
  *     fs_read_field / fs_write_field move the rows the slab owns ([plane][r1-r0][W]).
- * RCCL is loaded at run time (a librccl already in the process wins, else FS_RCCL_LIBRARY, else the
+ * RCCL is loaded at run time (FS_RCCL_LIBRARY if set, else a librccl already in the process, else the
  * default search path), so single-GPU hosts need none.
  * ---------------------------------------------------------------------- */
 typedef struct fs_comm fs_comm;
