@@ -163,6 +163,45 @@ def slab_selfcheck(dist, rank, world, local_rank):
     return verdict[0]
 
 
+def config4_extra(world, rank, local_rank, dist, frames=10, warm=4):
+    """Untimed-by-the-driver extra, reported beside the main line at every N: the 16384^2 grid of config 4
+    (strong scaling: the SAME grid on 1 GPU or split into N row slabs, always eight pointers), a few frames.
+    t_1 / (N t_N) of these figures across the driver's N = 1, 2, 4, 8 runs is the strong-scaling efficiency
+    north_star asks for."""
+    import torch
+    wl = WORKLOADS["config4"]
+    W, H, params = wl["W"], wl["H"], wl["params"]
+    if world == 1:
+        s, _ = make_single(W, H, params, 0)
+        step = lambda f: frame_single(s, None, f, W, H, 8)   # noqa: E731
+        sync = lambda: (s.sync(), torch.cuda.synchronize())   # noqa: E731
+    else:
+        from fluidsolver_amd.native_slabs import RcclSlab
+        s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
+        step = lambda f: s.frame(f, n_pointers=8)   # noqa: E731
+        sync = lambda: (s.sync(), torch.cuda.synchronize(), dist.barrier())   # noqa: E731
+    for f in range(warm):
+        step(f)
+    sync()
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        step(f)
+    sync()
+    el = time.perf_counter() - t0
+    out = {"grid": [W, H], "frames": frames, "pointers": 8}
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        st = s.stats
+        out.update(last_advect_halo=s.last_halo, advection_replans=st["redo"],
+                   halo_rows_sent_per_frame=st["rows_sent"] / float(max(1, st["frames"])))
+    s.close()
+    out.update(ms_per_frame=el * 1e3 / frames, frames_per_s=frames / el,
+               gcell_updates_per_s=W * H * frames / el / 1e9)
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/traffic.json,
     collected on config 2 by scripts/profile_round.sh); null for any other workload."""
@@ -241,7 +280,7 @@ def main():
         # results either way (bit-identical fields), every rank takes the same decision (max over ranks).
         forced = os.environ.get("FS_BENCH_SLAB_OVERLAP")
         ab, f0 = {}, 0
-        for mode in ((1, 0) if forced is None else (int(forced),)):
+        for mode in ((0, 1) if forced is None else (int(forced),)):   # plain first: the halo history is warm for the guess
             s.set_overlap(mode)
             for f in range(f0, f0 + 4):
                 step(f)
@@ -321,6 +360,12 @@ def main():
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
                        "overlap": bool(overlap), "advection_replans": st["redo"],
                        "untimed_ab_ms_per_frame": {"overlap": ab.get(1), "plain": ab.get(0)}}
+    if args.workload == "config2" and os.environ.get("FS_BENCH_NO_CONFIG4") != "1":
+        try:
+            s.close()
+            out["config4_strong"] = config4_extra(world if slabs else 1, rank, local_rank, dist if slabs else None)
+        except Exception as e:   # the extra must never cost the main line
+            out["config4_strong"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if slabs:
