@@ -12,8 +12,8 @@ namespace fs {
 
 int config_set_block_depth(int op, int v);
 int config_get_block_depth(int op);
-int config_set_tile_variant(int v);
-int config_get_tile_variant();
+int config_set_tile_variant(int op, int v);
+int config_get_tile_variant(int op);
 int config_set_stagger(int ticks, int mode);
 int config_get_stagger();
 
@@ -348,7 +348,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     case FS_OPT_FUSE: c->fuse = value ? 1 : 0; break;
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:
-        if (fs::config_set_tile_variant(value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
+        if (fs::config_set_tile_variant(-1, value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
@@ -600,7 +600,8 @@ int fs_config_set(int key, int value)
     if (key == FS_OPT_BLOCK_DEPTH) return fs::config_set_block_depth(-1, value);
     if (key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_set_block_depth(0, value);
     if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_set_block_depth(1, value);
-    if (key == FS_OPT_TILE_VARIANT) return fs::config_set_tile_variant(value);
+    if (key == FS_OPT_TILE_VARIANT) return fs::config_set_tile_variant(-1, value);
+    if (key == FS_OPT_TILE_VARIANT_DIFFUSE) return fs::config_set_tile_variant(1, value);
     if (key == FS_OPT_STAGGER) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(value, -1);
     if (key == FS_OPT_STAGGER_MODE) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(-1, value);
     return FS_ERR_INVALID;
@@ -609,7 +610,8 @@ int fs_config_get(int key)
 {
     if (key == FS_OPT_BLOCK_DEPTH || key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_get_block_depth(0);
     if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_get_block_depth(1);
-    if (key == FS_OPT_TILE_VARIANT) return fs::config_get_tile_variant();
+    if (key == FS_OPT_TILE_VARIANT) return fs::config_get_tile_variant(0);
+    if (key == FS_OPT_TILE_VARIANT_DIFFUSE) return fs::config_get_tile_variant(1);
     if (key == FS_OPT_STAGGER) return fs::config_get_stagger();
     return FS_ERR_INVALID;
 }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 // Tile: 4 rows per lane x 16 waves (64 VGPRs, 8 waves per SIMD).  The sweeps are bound by VALU issue and by
 // the per-sweep barrier, and twice the waves hide both better than the larger register tiles do.
 static int g_block_depth[2] = {10, 8};   // [OP_PRESSURE], [OP_DIFFUSE]
-static int g_tile_variant = 4;   // index into the (R rows per lane, NW waves) table below
+static int g_tile_variant[2] = {4, 4};   // [op]: index into the (R rows per lane, NW waves) table below
 static int g_stagger = 0, g_stagger_mode = 0;
 
 template <int OP, int R, int NW, int MINW>
@@ -274,12 +274,14 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.stagger_mode = g_stagger_mode;
     // p in, p out and div of the rows in play, against ~3/4 of the 256 MiB Infinity Cache
     A.xcd_chunked = OP == OP_PRESSURE && 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) < 192.0 * 1024 * 1024;
-    switch (g_tile_variant) {
+    switch (g_tile_variant[OP]) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
     case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
     case 0: return launch_variant<OP, 8, 8, 4>(A, g, nplanes, stream);    // 256 x 64 tile, 512 threads
     case 5: return launch_variant<OP, 12, 8, 3>(A, g, nplanes, stream);   // 256 x 96 tile, 512 threads
+    case 6: return launch_variant<OP, 6, 16, 8>(A, g, nplanes, stream);   // 256 x 96 tile, 1024 threads, 8 waves/SIMD
+    case 7: return launch_variant<OP, 5, 16, 8>(A, g, nplanes, stream);   // 256 x 80 tile, 1024 threads, 8 waves/SIMD
     default: return launch_variant<OP, 4, 16, 8>(A, g, nplanes, stream);  // 256 x 64 tile, 1024 threads
     }
 }
@@ -333,13 +335,14 @@ int config_set_block_depth(int op, int v)   // op < 0: both loops
     return FS_OK;
 }
 int config_get_block_depth(int op) { return g_block_depth[op == 1 ? 1 : 0]; }
-int config_set_tile_variant(int v)
+int config_set_tile_variant(int op, int v)   // op < 0: both loops
 {
-    if (v < 0 || v > 5) return FS_ERR_INVALID;
-    g_tile_variant = v;
+    if (v < 0 || v > 7 || op > 1) return FS_ERR_INVALID;
+    if (op < 0) g_tile_variant[0] = g_tile_variant[1] = v;
+    else g_tile_variant[op] = v;
     return FS_OK;
 }
-int config_get_tile_variant() { return g_tile_variant; }
+int config_get_tile_variant(int op) { return g_tile_variant[op == 1 ? 1 : 0]; }
 int config_set_stagger(int ticks, int mode)
 {
     if (ticks >= 0) g_stagger = ticks;

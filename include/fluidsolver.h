@@ -215,11 +215,12 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */
+       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* fs_config_set/get only: tile shape of the diffuse loops alone */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
                                      depth); 0 = exchange, wait, compute */
        FS_OPT_TILE_VARIANT = 3    /* Jacobi tile shape (rows per lane x waves): 0 = 8x8, 1 = 16x8,
-                                     2 = 8x16, 3 = 16x4, 4 = 4x16 (default), 5 = 12x8 */ };
+                                     2 = 8x16, 3 = 16x4, 4 = 4x16 (default), 5 = 12x8, 6 = 6x16, 7 = 5x16 */ };
 
 /* FluidSolver.init() + setResolution (Solver:240-255, :322-343): allocates the fields
  * of a width x height grid on HIP device `device`, all zero (clearTextures :348-366). */

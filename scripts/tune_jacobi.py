@@ -16,11 +16,11 @@ s.solverIterations = N
 rng = np.random.default_rng(0)
 s.write_field(L.FIELD_DIVERGENCE, rng.uniform(-1, 1, (1, H, W)).astype(np.float32))
 s.write_field(L.FIELD_VELOCITY, rng.uniform(-1, 1, (2, H, W)).astype(np.float32))
-names = {0: "8x8", 1: "16x8", 2: "8x16", 3: "16x4", 4: "4x16", 5: "12x8"}
-th = {0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 96}
+names = {0: "8x8", 1: "16x8", 2: "8x16", 3: "16x4", 4: "4x16", 5: "12x8", 6: "6x16", 7: "5x16"}
+th = {0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 96, 6: 96, 7: 80}
 ms = C.c_float()
 res = []
-VARS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else range(6)
+VARS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else range(8)
 for var in VARS:
     for depth in (5, 7, 8, 10, 12, 14, 16, 20):
         if th[var] - 2 * depth < 8:

@@ -246,7 +246,7 @@ def test_block_depth_does_not_change_bits(lib, oracle, depth):
         lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("depth", [1, 5, 10])
 def test_every_tile_variant_matches_the_oracle(lib, oracle, variant, depth):
     # every register-tile shape (rows per lane x waves) of the blocked kernel, both loops, edge and interior tiles
