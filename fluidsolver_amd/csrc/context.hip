@@ -281,7 +281,10 @@ int fs_destroy(fs_ctx *c)
     for (int i = 0; i < F_COUNT; ++i) { (void)hipFree(c->f[i].buf[0]); (void)hipFree(c->f[i].buf[1]); }
     (void)hipFree(c->display); (void)hipFree(c->err_flag); (void)hipFree(c->cfl_dev);
     if (c->cfl_host) (void)hipHostFree(c->cfl_host);
-    for (int i = 0; i < 7; ++i) (void)hipFree(c->part[i]);
+    for (int i = 0; i < 7; ++i) { (void)hipFree(c->part[i]); (void)hipFree(c->part_t[i]); (void)hipFree(c->outbox[i]); }
+    (void)hipFree(c->tr_counts_dev); (void)hipFree(c->tr_matrix_dev);
+    if (c->tr_counts_host) (void)hipHostFree(c->tr_counts_host);
+    if (c->tr_matrix_host) (void)hipHostFree(c->tr_matrix_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -540,20 +543,64 @@ int fs_stage(fs_ctx *c, int stage, int n)
     return rc ? ctx_fail(c, rc) : FS_OK;
 }
 
+int fs_particles_reserve(fs_ctx *c, long capacity)
+{
+    CTX(c);
+    if (capacity < 0) { fs::set_error("negative tracer capacity"); return ctx_fail(c, FS_ERR_INVALID); }
+    TRYHIP(c, hipStreamSynchronize(c->stream));
+    const bool slab = c->world > 1;
+    for (int i = 0; i < 7; ++i) {
+        (void)hipFree(c->part[i]); (void)hipFree(c->part_t[i]); (void)hipFree(c->outbox[i]);
+        c->part[i] = c->part_t[i] = c->outbox[i] = nullptr;
+    }
+    c->n_particles = 0;
+    c->max_particles = 0;
+    drop_graphs(c);
+    for (int i = 0; i < 7 && capacity > 0; ++i) {
+        TRYHIP(c, hipMalloc((void **)&c->part[i], (size_t)capacity * sizeof(float)));
+        if (slab) {
+            TRYHIP(c, hipMalloc((void **)&c->part_t[i], (size_t)capacity * sizeof(float)));
+            TRYHIP(c, hipMalloc((void **)&c->outbox[i], (size_t)capacity * sizeof(float)));
+        }
+    }
+    if (slab && capacity > 0 && !c->tr_counts_dev) {
+        const size_t w = (size_t)c->world;
+        TRYHIP(c, hipMalloc((void **)&c->tr_counts_dev, w * sizeof(int)));
+        TRYHIP(c, hipHostMalloc((void **)&c->tr_counts_host, w * sizeof(int), hipHostMallocDefault));
+        TRYHIP(c, hipMalloc((void **)&c->tr_matrix_dev, w * w * sizeof(float)));
+        TRYHIP(c, hipHostMalloc((void **)&c->tr_matrix_host, w * w * sizeof(float), hipHostMallocDefault));
+    }
+    c->max_particles = capacity;
+    return FS_OK;
+}
+
+int fs_set_particle_params(fs_ctx *c, const fs_particle_params *pp)
+{
+    CTX(c);
+    if (!pp) { fs::set_error("particle params is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
+    if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
+    return FS_OK;
+}
+
+// One GPU: the n tracers.  A slab: every rank is handed the SAME n tracers and keeps the index block
+// [rank n / world, (rank+1) n / world); the next tracer step moves each to the rank that owns its row.
 int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const float *vx, const float *vy,
                      const float *life, const float *mass, const float *age)
 {
     CTX(c);
-    SINGLE(c, "tracers");
-    if (n < 0 || n > c->max_particles) { fs::set_error("particle count %ld exceeds capacity %ld", n, c->max_particles); return ctx_fail(c, FS_ERR_INVALID); }
+    if (n < 0) { fs::set_error("negative particle count"); return ctx_fail(c, FS_ERR_INVALID); }
+    const long lo = c->world > 1 ? (long)((__int128)n * c->rank / c->world) : 0;
+    const long hi = c->world > 1 ? (long)((__int128)n * (c->rank + 1) / c->world) : n;
+    const long mine = hi - lo;
+    if (mine > c->max_particles) { fs::set_error("particle count %ld exceeds capacity %ld", mine, c->max_particles); return ctx_fail(c, FS_ERR_INVALID); }
     const float *src[7] = {px, py, vx, vy, life, mass, age};
     TRYHIP(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 7 && n > 0; ++i) {
+    for (int i = 0; i < 7 && mine > 0; ++i) {
         if (!src[i]) { fs::set_error("NULL particle array %d", i); return ctx_fail(c, FS_ERR_INVALID); }
-        TRYHIP(c, hipMemcpy(c->part[i], src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        TRYHIP(c, hipMemcpy(c->part[i], src[i] + lo, (size_t)mine * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (n != c->n_particles) drop_graphs(c);
-    c->n_particles = n;
+    if (mine != c->n_particles) drop_graphs(c);
+    c->n_particles = mine;
     return FS_OK;
 }
 
@@ -571,10 +618,30 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
 
 long fs_particles_count(fs_ctx *c) { return c ? c->n_particles : 0; }
 
+int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha)
+{
+    CTX(c);
+    const long n = c->n_particles;
+    if (n == 0) return FS_OK;
+    if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
+    float *xy = nullptr, *al = nullptr;
+    TRYHIP(c, hipMalloc((void **)&xy, (size_t)n * 5 * sizeof(float)));
+    al = xy + 4 * n;
+    int rc = fs_k_particle_lines(n, c->part[0], c->part[1], c->part[2], c->part[3], c->part[4], viewportW, viewportH,
+                                 particleScale, xy, al, c->stream);
+    hipError_t e = rc ? hipSuccess : hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpy(host_xy4, xy, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess) e = hipMemcpy(host_alpha, al, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(xy);
+    if (rc) return ctx_fail(c, rc);
+    if (e != hipSuccess) return ctx_fail(c, fs::hip_fail(e, "fs_particle_lines"));
+    return FS_OK;
+}
+
 int fs_particles_update(fs_ctx *c, const fs_particle_params *pp)
 {
     CTX(c);
-    SINGLE(c, "tracers");
+    SINGLE(c, "fs_particles_update (on a slab the tracer step is part of fs_step, FS_OPT_WITH_PARTICLES)");
     if (pp) {
         if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
     }

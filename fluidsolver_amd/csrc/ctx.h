@@ -30,7 +30,7 @@ struct Xfer {
     int field, bufidx, depth;   // refresh the ghost rows of f[field].buf[bufidx] to `depth` rows
 };
 
-enum { STEP_COMPUTE = 0, STEP_EXCHANGE = 1, STEP_CFL_REDUCE = 2, STEP_JOIN = 3 };
+enum { STEP_COMPUTE = 0, STEP_EXCHANGE = 1, STEP_CFL_REDUCE = 2, STEP_JOIN = 3, STEP_TRACERS = 4 };
 // An exchange runs on the context's exchange stream.  Its completion event is a "slot"; the main
 // stream joins a slot (waits for the event) before the first kernel that needs the rows.
 enum { SLOT_VEL = 0, SLOT_DYE = 1, SLOT_SYNC = 2, SLOT_COUNT = 3 };
@@ -108,6 +108,15 @@ struct fs_ctx {
     long max_particles = 0, n_particles = 0;
     float *part[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     fs_particle_params pparams{};
+    // tracers on a slab: partner arrays (the "keep" side of a re-homing), per-destination outboxes, counters
+    float *part_t[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *outbox[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *tr_counts_dev = nullptr;       // `world` ints: counts, then cursors
+    int *tr_counts_host = nullptr;      // pinned, `world` ints: how many of my tracers go to each rank
+    float *tr_matrix_dev = nullptr;     // RCCL: world x world counts as floats, summed over ranks
+    float *tr_matrix_host = nullptr;    // pinned
+    std::vector<long> tr_send_off, tr_recv_cnt;
+    long stat_migrated = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
     char error[512] = "";
 };

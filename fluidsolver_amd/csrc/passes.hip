@@ -13,6 +13,7 @@
 // -ffp-contract=off so no FMA is formed and results are bit-identical to the oracle.
 #include "common.h"
 #include <math.h>
+#include <stdint.h>
 
 namespace fs {
 
@@ -400,6 +401,89 @@ __global__ __launch_bounds__(256) void k_particles(GK g, const float *__restrict
     life[i] = l;
 }
 
+// tracer line vertices, vertex shader particleVertex Shaders:446-476: (pos - vel*scale, pos) in NDC, alpha = life
+__global__ __launch_bounds__(256) void k_particle_lines(long n, const float *__restrict__ px, const float *__restrict__ py,
+                                                        const float *__restrict__ vx, const float *__restrict__ vy,
+                                                        const float *__restrict__ life, float vw, float vh, float scale,
+                                                        float4 *__restrict__ out_xy, float *__restrict__ out_alpha)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = px[i], y = py[i];
+    const float sx = x - vx[i] * scale, sy = y - vy[i] * scale;            // :462
+    float4 o;
+    o.x = (sx / vw) * 2.0f - 1.0f;                                          // :468
+    o.y = -((sy / vh) * 2.0f - 1.0f);                                       // :469
+    o.z = (x / vw) * 2.0f - 1.0f;                                           // :464
+    o.w = -((y / vh) * 2.0f - 1.0f);
+    out_xy[i] = o;
+    out_alpha[i] = life[i];                                                 // :472
+}
+
+// ---------------------------------------------------------------------------
+// Tracers on row slabs (no counterpart in the reference): a tracer lives on the rank
+// that owns the grid row its velocity lookup reads (Solver:651).  Before each update the tracers are
+// re-homed: count per destination, then scatter into a "keep" set (partner arrays) and per-destination
+// outboxes.  One atomic per destination and WAVE, not per tracer.
+// ---------------------------------------------------------------------------
+struct SlabSplit {
+    int world, rank, base, rem;   // rows per rank = base (+1 for the first rem ranks), see slab_rows()
+};
+__device__ __forceinline__ int tracer_dest(const fs_particle_params &pp, const GK &g, const SlabSplit sp, float y, float l)
+{
+    if (l == 0.0f) return sp.rank;                            // dead slots never move
+    const float invH = 1.0f / pp.windowH;                     // the same operations as k_particles
+    const float gh = (float)g.H;
+    const float ny = y * invH;
+    const int cy = (int)fmaxf(0.0f, fminf(gh - 1.0f, ny * gh));   // Solver:651
+    const int big = sp.rem * (sp.base + 1);
+    return cy < big ? cy / (sp.base + 1) : sp.rem + (cy - big) / sp.base;
+}
+// slot for this lane among the lanes of the wave with the same destination: base from one atomicAdd
+// by the first such lane (counting only when cursors is a counter array: same code)
+__device__ __forceinline__ int wave_slot(int *cursor, int dest, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    int slot = -1;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int d = __shfl(dest, leader);
+        const unsigned long long same = __ballot(valid && dest == d);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[d], __popcll(same));
+        base = __shfl(base, leader);
+        if (valid && dest == d) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+__global__ __launch_bounds__(256) void k_tracer_count(GK g, fs_particle_params pp, SlabSplit sp, long n,
+                                                      const float *__restrict__ py, const float *__restrict__ life,
+                                                      int *__restrict__ counts)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int dest = valid ? tracer_dest(pp, g, sp, py[i], life[i]) : 0;
+    (void)wave_slot(counts, dest, valid);
+}
+struct TracerArrays {
+    float *a[7];
+};
+__global__ __launch_bounds__(256) void k_tracer_scatter(GK g, fs_particle_params pp, SlabSplit sp, long n,
+                                                        TracerArrays in, TracerArrays keep, TracerArrays outbox,
+                                                        int *__restrict__ cursors)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int dest = valid ? tracer_dest(pp, g, sp, in.a[1][i], in.a[4][i]) : 0;
+    const int slot = wave_slot(cursors, dest, valid);   // cursors start at the destination's outbox offset (0 for me)
+    if (!valid) return;
+    const TracerArrays &to = dest == sp.rank ? keep : outbox;
+#pragma unroll
+    for (int f = 0; f < 7; ++f) to.a[f][slot] = in.a[f][i];
+}
+
 // max |plane| over rows [yb,ye): wave shuffle reduce, one atomicMax per wave (non-negative
 // floats order like their bit patterns).
 __global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const float *__restrict__ p, unsigned *out)
@@ -621,13 +705,68 @@ int fs_k_particles_update(const fs_grid *g, const float *u, const float *v, cons
     REQUIRE(n >= 0, "negative particle count");
     if (n == 0) return FS_OK;
     REQUIRE(px && py && vx && vy && life && mass && age, "null particle array");
-    REQUIRE(g->y0 == 0 && g->rows == g->height, "tracers need the whole grid on this GPU");
+    // a slab passes only tracers whose lookup row it owns (fs_tracer_rehome); a lookup outside the buffer is
+    // clamped into it, never out of bounds
     // Part:262-268
     float eff = pp->linkToViscosity ? 0.1f + (pp->viscosity / 0.01f) * 0.9f : pp->fluidForce;
     unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_particles, dim3(blocks), dim3(256), 0, STREAM, make_gk(g), u, v, *pp, eff, n, px, py, vx,
                        vy, life, mass, age);
     FS_LAUNCH_CHECK("k_particles");
+    return FS_OK;
+}
+
+int fs_k_particle_lines(long n, const float *px, const float *py, const float *vx, const float *vy, const float *life,
+                        float viewportW, float viewportH, float particleScale, float *out_xy4, float *out_alpha,
+                        void *stream)
+{
+    REQUIRE(n >= 0, "negative particle count");
+    if (n == 0) return FS_OK;
+    REQUIRE(px && py && vx && vy && life && out_xy4 && out_alpha, "null pointer");
+    REQUIRE(((uintptr_t)out_xy4 & 15) == 0, "out_xy4 must be 16-byte aligned");
+    hipLaunchKernelGGL(k_particle_lines, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, n, px, py, vx, vy, life,
+                       viewportW, viewportH, particleScale, reinterpret_cast<float4 *>(out_xy4), out_alpha);
+    FS_LAUNCH_CHECK("k_particle_lines");
+    return FS_OK;
+}
+
+static fs::SlabSplit split_of(const fs_grid *g, int world, int rank)
+{
+    return fs::SlabSplit{world, rank, g->height / world, g->height % world};
+}
+static fs::TracerArrays arrays_of(float *const a[7])
+{
+    fs::TracerArrays t;
+    for (int i = 0; i < 7; ++i) t.a[i] = a[i];
+    return t;
+}
+
+int fs_k_tracer_count(const fs_grid *g, const fs_particle_params *pp, int world, int rank, long n, const float *py,
+                      const float *life, int *counts_dev, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(pp && counts_dev && world >= 1 && rank >= 0 && rank < world && g->height / world >= 1, "bad arguments");
+    REQUIRE(n >= 0, "negative particle count");
+    if (n == 0) return FS_OK;
+    REQUIRE(py && life, "null particle array");
+    hipLaunchKernelGGL(k_tracer_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, make_gk(g), *pp,
+                       split_of(g, world, rank), n, py, life, counts_dev);
+    FS_LAUNCH_CHECK("k_tracer_count");
+    return FS_OK;
+}
+
+int fs_k_tracer_scatter(const fs_grid *g, const fs_particle_params *pp, int world, int rank, long n,
+                        float *const in[7], float *const keep[7], float *const outbox[7], int *cursors_dev,
+                        void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(pp && cursors_dev && in && keep && outbox && world >= 1 && rank >= 0 && rank < world, "bad arguments");
+    REQUIRE(n >= 0, "negative particle count");
+    if (n == 0) return FS_OK;
+    for (int i = 0; i < 7; ++i) REQUIRE(in[i] && keep[i] && outbox[i], "null particle array");
+    hipLaunchKernelGGL(k_tracer_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, make_gk(g), *pp,
+                       split_of(g, world, rank), n, arrays_of(in), arrays_of(keep), arrays_of(outbox), cursors_dev);
+    FS_LAUNCH_CHECK("k_tracer_scatter");
     return FS_OK;
 }
 

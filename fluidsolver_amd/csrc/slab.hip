@@ -382,6 +382,12 @@ struct Planner {
                   *a5 = c->part[5], *a6 = c->part[6];
             compute("particles", g, 0, [=]() { return fs_k_particles_update(&g, u, v, &pp, n, a0, a1, a2, a3, a4, a5, a6, st); });
         }
+        if (c->with_particles && multi) {                                             // collective: every rank plans it
+            Step s;
+            s.kind = STEP_TRACERS;
+            s.what = "tracers";
+            c->steps.push_back(std::move(s));
+        }
     }
 };
 
@@ -630,6 +636,96 @@ int wait_cfl(fs_ctx *c)
     return FS_OK;
 }
 
+// Tracers of a slab: re-home (count per destination -> counts of everybody -> scatter into keep set and
+// outboxes -> move the outboxes), then ParticleSystem.update() on the tracers now living here.  Host-synchronous
+// (three small waits per frame): a tracer step is cheap next to a frame and no config times it on slabs.
+//   0  count my tracers per home rank; RCCL: sum the world x world count matrix over the ranks
+//   1  everybody's counts are known: capacity check, outbox offsets, scatter
+//   2  move the outboxes (RCCL send/recv, or copies out of the peers' outboxes), swap, update
+int tracer_phase(fs_ctx *c, int phase)
+{
+    fs_comm *cm = c->comm;
+    if (!cm) { set_error("tracer step planned on a context without a communicator"); return FS_ERR_STATE; }
+    if (c->max_particles <= 0 || !c->tr_counts_dev) { set_error("tracers on a slab need fs_particles_reserve first"); return FS_ERR_STATE; }
+    const int W = c->world, me = c->rank;
+    const fs_grid g = grid_of(c, 0);
+    const long n = c->n_particles;
+    if (phase == 0) {
+        FS_HIP(hipMemsetAsync(c->tr_counts_dev, 0, (size_t)W * sizeof(int), c->stream));
+        int rc = fs_k_tracer_count(&g, &c->pparams, W, me, n, c->part[1], c->part[4], c->tr_counts_dev, c->stream);
+        if (rc) return rc;
+        FS_HIP(hipMemcpyAsync(c->tr_counts_host, c->tr_counts_dev, (size_t)W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(hipStreamSynchronize(c->stream));
+        if (cm->kind == 1) {
+            for (int i = 0; i < W * W; ++i) c->tr_matrix_host[i] = 0.0f;
+            for (int d = 0; d < W; ++d) c->tr_matrix_host[me * W + d] = (float)c->tr_counts_host[d];
+            FS_HIP(hipMemcpyAsync(c->tr_matrix_dev, c->tr_matrix_host, (size_t)W * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            FS_NCCL(g_rccl.AllReduce(c->tr_matrix_dev, c->tr_matrix_dev, (size_t)W * W, ncclFloat, ncclSum, (ncclComm_t)cm->nccl, c->stream));
+            FS_HIP(hipMemcpyAsync(c->tr_matrix_host, c->tr_matrix_dev, (size_t)W * W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            FS_HIP(hipStreamSynchronize(c->stream));
+        }
+        return FS_OK;
+    }
+    if (phase == 1) {
+        c->tr_recv_cnt.assign(W, 0);
+        c->tr_send_off.assign(W, 0);
+        long total = c->tr_counts_host[me], off = 0;
+        for (int q = 0; q < W; ++q) {
+            if (q == me) continue;
+            c->tr_recv_cnt[q] = cm->kind == 1 ? (long)c->tr_matrix_host[q * W + me] : (long)cm->members[q]->tr_counts_host[me];
+            total += c->tr_recv_cnt[q];
+            c->tr_send_off[q] = off;
+            off += c->tr_counts_host[q];
+        }
+        if (total > c->max_particles) {
+            set_error("rank %d would hold %ld tracers, its capacity is %ld (fs_particles_reserve)", me, total, c->max_particles);
+            return FS_ERR_NOMEM;
+        }
+        std::vector<int> cursors(W);
+        for (int q = 0; q < W; ++q) cursors[q] = q == me ? 0 : (int)c->tr_send_off[q];
+        FS_HIP(hipMemcpy(c->tr_counts_dev, cursors.data(), (size_t)W * sizeof(int), hipMemcpyHostToDevice));
+        return fs_k_tracer_scatter(&g, &c->pparams, W, me, n, c->part, c->part_t, c->outbox, c->tr_counts_dev, c->stream);
+    }
+    const long keep = c->tr_counts_host[me];
+    long at = keep, moved = 0;
+    if (cm->kind == 1) {
+        FS_NCCL(g_rccl.GroupStart());
+        for (int q = 0; q < W; ++q) {
+            if (q == me) continue;
+            for (int f = 0; f < 7; ++f) {
+                ncclResult_t r = ncclSuccess;
+                if (c->tr_counts_host[q] > 0)
+                    r = g_rccl.Send(c->outbox[f] + c->tr_send_off[q], (size_t)c->tr_counts_host[q], ncclFloat, q, (ncclComm_t)cm->nccl, c->stream);
+                if (r == ncclSuccess && c->tr_recv_cnt[q] > 0)
+                    r = g_rccl.Recv(c->part_t[f] + at, (size_t)c->tr_recv_cnt[q], ncclFloat, q, (ncclComm_t)cm->nccl, c->stream);
+                if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(r, "tracer send/recv"); }
+            }
+            at += c->tr_recv_cnt[q];
+            moved += c->tr_recv_cnt[q];
+        }
+        FS_NCCL(g_rccl.GroupEnd());
+    } else {
+        int rc = sync_members(cm);   // every rank's scatter is complete
+        if (rc) return rc;
+        FS_HIP(hipSetDevice(c->device));
+        for (int q = 0; q < W; ++q) {
+            if (q == me || c->tr_recv_cnt[q] == 0) continue;
+            const fs_ctx *peer = cm->members[q];
+            for (int f = 0; f < 7; ++f)
+                FS_HIP(hipMemcpy(c->part_t[f] + at, peer->outbox[f] + peer->tr_send_off[me], (size_t)c->tr_recv_cnt[q] * sizeof(float),
+                                 hipMemcpyDeviceToDevice));
+            at += c->tr_recv_cnt[q];
+            moved += c->tr_recv_cnt[q];
+        }
+    }
+    for (int f = 0; f < 7; ++f) std::swap(c->part[f], c->part_t[f]);
+    c->n_particles = at;
+    c->stat_migrated += moved;
+    const float *u = c->f[F_VEL].p(), *v = u + c->plane;
+    return fs_k_particles_update(&g, u, v, &c->pparams, c->n_particles, c->part[0], c->part[1], c->part[2], c->part[3],
+                                 c->part[4], c->part[5], c->part[6], c->stream);   // MetalView.swift:155 -> Part:242
+}
+
 int exec_phase(fs_ctx *c, const Step &s, int phase)
 {
     switch (s.kind) {
@@ -637,6 +733,7 @@ int exec_phase(fs_ctx *c, const Step &s, int phase)
     case STEP_EXCHANGE: return exchange_phase(c, s, phase);
     case STEP_CFL_REDUCE: return cfl_phase(c, phase);
     case STEP_JOIN: return phase == 0 ? join_slot(c, s.slot) : FS_OK;
+    case STEP_TRACERS: return tracer_phase(c, phase);
     }
     return FS_ERR_STATE;
 }
@@ -670,7 +767,8 @@ int exec_all(fs_ctx **cs, int n)
             return ctx_fail(cs[r], FS_ERR_STATE);
         }
     for (size_t i = 0; i < count; ++i) {
-        const int phases = cs[0]->steps[i].kind == STEP_EXCHANGE || cs[0]->steps[i].kind == STEP_CFL_REDUCE ? 3 : 1;
+        const int kind = cs[0]->steps[i].kind;
+        const int phases = kind == STEP_EXCHANGE || kind == STEP_CFL_REDUCE || kind == STEP_TRACERS ? 3 : 1;
         for (int phase = 0; phase < phases; ++phase)
             for (int r = 0; r < n; ++r) {
                 fs_ctx *c = cs[r];
@@ -762,7 +860,7 @@ static void append_plan(const fs_ctx *c, std::string &out)
         if (s.kind == STEP_COMPUTE) {
             snprintf(line, sizeof(line), "%s %d %d %d\n", s.what, s.yb, s.ye, s.n);
             out += line;
-        } else if (s.kind == STEP_JOIN) {
+        } else if (s.kind == STEP_JOIN || s.kind == STEP_TRACERS) {
             out += s.what;
             out += "\n";
         } else if (s.kind == STEP_EXCHANGE) {
@@ -904,10 +1002,11 @@ int fs_slab_info(fs_ctx *c, int info[6])
     return FS_OK;
 }
 
-int fs_slab_stats(fs_ctx *c, long stats[4])
+int fs_slab_stats(fs_ctx *c, long stats[5])
 {
     if (!c || !stats) return FS_ERR_INVALID;
     stats[0] = c->stat_exchanges; stats[1] = c->stat_rows; stats[2] = c->stat_frames; stats[3] = c->stat_redo;
+    stats[4] = c->stat_migrated;
     return FS_OK;
 }
 

@@ -100,6 +100,12 @@ SIGNATURES = {
     "fs_default_particle_params": (_i, [C.POINTER(ParticleParams), _f, _f]),
     "fs_particles_update": (_i, [_p, C.POINTER(ParticleParams)]),
     "fs_particles_count": (_l, [_p]),
+    "fs_particles_reserve": (_i, [_p, _l]),
+    "fs_particle_lines": (_i, [_p, _f, _f, _f, _p, _p]),
+    "fs_k_particle_lines": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p]),
+    "fs_set_particle_params": (_i, [_p, C.POINTER(ParticleParams)]),
+    "fs_k_tracer_count": (_i, [_G, C.POINTER(ParticleParams), _i, _i, _l, _p, _p, _p, _p]),
+    "fs_k_tracer_scatter": (_i, [_G, C.POINTER(ParticleParams), _i, _i, _l, _p, _p, _p, _p, _p]),
     "fs_comm_unique_id": (_i, [_p]),
     "fs_comm_create_rccl": (_i, [_i, _i, _i, _p, C.POINTER(_p)]),
     "fs_comm_create_local": (_i, [_i, C.POINTER(_p)]),

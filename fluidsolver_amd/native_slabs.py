@@ -47,6 +47,7 @@ class _Slab:
         self.W, self.H = int(W), int(H)
         self.radius = float(radius)
         self.deltaTime = float(params[2])
+        self.viscosity = float(params[0])
         ctx = C.c_void_p()
         L.check(self.lib.fs_create_slab(self.W, self.H, int(device), comm, int(rank), -1 if ghost is None else int(ghost),
                                         C.byref(ctx)))
@@ -96,9 +97,35 @@ class _Slab:
 
     @property
     def stats(self):
-        st = (C.c_long * 4)()
+        st = (C.c_long * 5)()
         L.check(self.lib.fs_slab_stats(self.ctx, st))
-        return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2], "redo": st[3]}
+        return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2], "redo": st[3], "tracers_received": st[4]}
+
+    # ---- tracers: each lives on the rank that owns the row its lookup reads ----
+    def particles_reserve(self, capacity, window=None, **params):
+        """Room for `capacity` tracers on THIS rank; turns the tracer step of update() on.  params: fields of
+        fs_particle_params (momentum, fluidForce, fluidDecayRate, linkToViscosity) that differ from the defaults."""
+        L.check(self.lib.fs_particles_reserve(self.ctx, int(capacity)), self.ctx)
+        pp = L.ParticleParams()
+        w = window or (float(self.W), float(self.H))
+        L.check(self.lib.fs_default_particle_params(C.byref(pp), float(w[0]), float(w[1])))
+        pp.viscosity = self.viscosity
+        for k, v in params.items():
+            setattr(pp, k, type(getattr(pp, k))(v))
+        L.check(self.lib.fs_set_particle_params(self.ctx, C.byref(pp)), self.ctx)
+        L.check(self.lib.fs_set_option(self.ctx, L.OPT_WITH_PARTICLES, 1), self.ctx)
+
+    def particles_set(self, px, py, vx, vy, life, mass, age):
+        """The SAME global arrays on every rank; this rank keeps its index block until the next update()."""
+        arrs = [np.ascontiguousarray(a, dtype=F) for a in (px, py, vx, vy, life, mass, age)]
+        L.check(self.lib.fs_particles_set(self.ctx, len(arrs[0]), *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
+
+    def particles_get(self):
+        """This rank's tracers, [7, n] (px, py, vx, vy, life, mass, age), in no particular order."""
+        n = self.lib.fs_particles_count(self.ctx)
+        out = np.empty((7, n), dtype=F)
+        L.check(self.lib.fs_particles_get(self.ctx, n, *[out[i].ctypes.data_as(C.c_void_p) for i in range(7)]), self.ctx)
+        return out
 
 
 class RcclSlab(_Slab):

@@ -253,5 +253,16 @@ class ParticleSystem:
         pp = self._pparams(windowSize)
         L.check(self._lib.fs_particles_update(s.ctx, C.byref(pp)), s.ctx)
 
+    def lineVertices(self, viewportSize, particleScale=None):
+        """What render(in:viewportSize:) draws (:341-363 -> particleVertex, Shaders:446-476): per tracer the line
+        (pos - vel * particleScale, pos) in NDC as [n, 4] = (x0, y0, x1, y1), and alpha = life as [n]."""
+        n = self.particleCount
+        xy, alpha = np.empty((n, 4), F), np.empty(n, F)
+        scale = self.particleSize if particleScale is None else particleScale     # :356 passes particleSize
+        L.check(self._lib.fs_particle_lines(self._solver.ctx, float(viewportSize[0]), float(viewportSize[1]), float(scale),
+                                            xy.ctypes.data_as(C.c_void_p), alpha.ctypes.data_as(C.c_void_p)),
+                self._solver.ctx)
+        return xy, alpha
+
     def reset(self):  # :366-370
         self.set_arrays(*[np.zeros(0, F) for _ in range(7)])

@@ -170,6 +170,27 @@ int fs_k_particles_update(const fs_grid *g, const float *u, const float *v,
                           float *px, float *py, float *vx, float *vy,
                           float *life, const float *mass, float *age, void *stream);
 
+/* replaces the vertex shader particleVertex, Shaders:446-476 (buffer 1 viewportSize, buffer 2 particleScale), as a
+ * compute pass: per tracer the two line vertices in NDC, out_xy4 = n x (x0, y0, x1, y1) with
+ * (x0, y0) = ndc(pos - vel * particleScale), (x1, y1) = ndc(pos), ndc(p) = (p / viewport) * 2 - 1 with y flipped,
+ * and out_alpha = life (the colour is constant white, :472).  Device pointers; out_xy4 16-byte aligned. */
+int fs_k_particle_lines(long n, const float *px, const float *py, const float *vx, const float *vy, const float *life,
+                        float viewportW, float viewportH, float particleScale, float *out_xy4, float *out_alpha,
+                        void *stream);
+
+/* Tracers on row slabs; no counterpart in the reference.  A tracer lives on the rank that
+ * owns the grid row its velocity lookup reads (Solver:651); dead slots never move.  Arrays are the seven SoA
+ * planes in the order px, py, vx, vy, life, mass, age (device pointers).
+ *   fs_k_tracer_count   counts_dev[d] += tracers of `in` whose home is rank d (counts_dev: `world` ints)
+ *   fs_k_tracer_scatter copies every tracer to keep[...] (home == rank) or outbox[...] (home == d) at the slot
+ *                       taken from cursors_dev[d]++ -- preset cursors_dev[d] to rank d's outbox offset and
+ *                       cursors_dev[rank] to 0.  The order inside a destination is not deterministic. */
+int fs_k_tracer_count(const fs_grid *g, const fs_particle_params *pp, int world, int rank, long n,
+                      const float *py, const float *life, int *counts_dev, void *stream);
+int fs_k_tracer_scatter(const fs_grid *g, const fs_particle_params *pp, int world, int rank, long n,
+                        float *const in[7], float *const keep[7], float *const outbox[7], int *cursors_dev,
+                        void *stream);
+
 /* No counterpart in the reference (it has one GPU and no CFL logic): max |plane| over
  * rows [yb,ye), written as a float into *out_dev (device; must hold 0.0f beforehand).
  * Used to size the advection halo of a row slab: ceil(max|v_y| * dt) + 1 rows. */
@@ -270,6 +291,12 @@ int fs_particles_get(fs_ctx *ctx, long n, float *px, float *py, float *vx, float
 int fs_default_particle_params(fs_particle_params *pp, float windowW, float windowH);
 int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
 long fs_particles_count(fs_ctx *ctx);
+/* (Re)allocate room for `capacity` tracers on this context; existing tracers are dropped.  On a slab this is
+ * the only way to get tracer storage (capacity is per rank: leave headroom for tracers that migrate in). */
+/* Line vertices of the context's tracers (fs_k_particle_lines) into host arrays of 4 n and n floats. Blocking. */
+int fs_particle_lines(fs_ctx *ctx, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha);
+int fs_particles_reserve(fs_ctx *ctx, long capacity);
+int fs_set_particle_params(fs_ctx *ctx, const fs_particle_params *pp);
 
 /* -------------------------------------------------------------------------
  * Layer 3: row slabs across GPUs.  No counterpart in the reference (one MTLDevice, Solver:269);
@@ -306,10 +333,15 @@ int fs_comm_selftest(fs_comm *comm, int count);
 
 /* ghost_rows = capacity per interior side; < 0 picks one whole slab.  It bounds the advection halo
  * (FS_ERR_HALO from fs_step when ceil(max|v_y| dt) + 2 exceeds it); values above the slab height
- * are legal (rows then come from several ranks).  Tracers and fs_stage are single-GPU only. */
+ * are legal (rows then come from several ranks).  fs_stage is single-GPU only.
+ * Tracers on slabs: fs_particles_reserve(ctx, capacity per rank); fs_particles_set with the SAME global arrays on
+ * every rank (rank r keeps the index block [r n / world, (r+1) n / world)); FS_OPT_WITH_PARTICLES = 1 makes
+ * fs_step / fs_group_step re-home the tracers (each moves to the rank whose rows its lookup reads: counts by
+ * all-reduce, payload by send/recv) and then update them; fs_particles_get returns the rank's own tracers
+ * (fs_particles_count of them), in no particular order. */
 int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out);
 int fs_slab_info(fs_ctx *ctx, int info[6]);   /* r0, r1 (owned rows), b0, b1 (buffered rows), ghost capacity, last advection halo */
-int fs_slab_stats(fs_ctx *ctx, long stats[4]); /* exchange rounds, halo rows sent, frames, advection re-plans (halo guessed too small) */
+int fs_slab_stats(fs_ctx *ctx, long stats[5]); /* exchange rounds, halo rows sent, frames, advection re-plans (halo guessed too small), tracers received */
 int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
 /* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
  * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f;

@@ -437,6 +437,27 @@ void fo_particles_update(const fo_grid *g, const float *u, const float *v,
 }
 
 /* ------------------------------------------------------------------ */
+/* Tracer line vertices: vertex shader particleVertex, Shaders:446-476. */
+/* Two vertices per particle, start = pos - vel * particleScale (:462)  */
+/* and end = pos (:464), each mapped to NDC (pos / viewport) * 2 - 1    */
+/* with y flipped (:468-469); colour = white with alpha = life (:472).  */
+/* out_xy = n x (x0, y0, x1, y1); out_alpha = n.                        */
+/* ------------------------------------------------------------------ */
+void fo_particle_lines(long n, const float *px, const float *py, const float *vx, const float *vy,
+                       const float *life, float viewW, float viewH, float particleScale,
+                       float *out_xy, float *out_alpha)
+{
+    for (long i = 0; i < n; ++i) {
+        float sx = px[i] - vx[i] * particleScale, sy = py[i] - vy[i] * particleScale;   /* :462 */
+        out_xy[4 * i + 0] = (sx / viewW) * 2.0f - 1.0f;                                  /* :468 */
+        out_xy[4 * i + 1] = -((sy / viewH) * 2.0f - 1.0f);                               /* :469 */
+        out_xy[4 * i + 2] = (px[i] / viewW) * 2.0f - 1.0f;                               /* :464, :468 */
+        out_xy[4 * i + 3] = -((py[i] / viewH) * 2.0f - 1.0f);
+        out_alpha[i] = life[i];                                                          /* :472 */
+    }
+}
+
+/* ------------------------------------------------------------------ */
 unsigned fo_xorshift32(unsigned *state)
 {
     unsigned x = *state;

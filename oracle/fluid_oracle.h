@@ -102,6 +102,11 @@ void fo_particles_update(const fo_grid *g, const float *u, const float *v,
                          float *px, float *py, float *vx, float *vy,
                          float *life, float *mass, float *age);
 
+/* Shaders:446-476 particleVertex: line vertices (pos - vel*scale, pos) in NDC and alpha = life */
+void fo_particle_lines(long n, const float *px, const float *py, const float *vx, const float *vy,
+                       const float *life, float viewW, float viewH, float particleScale,
+                       float *out_xy, float *out_alpha);
+
 /* xorshift32 harness RNG (SURVEY 8(d) config 3 / Jacobi micro-benchmark). */
 unsigned fo_xorshift32(unsigned *state);
 void fo_fill_uniform(float *dst, long n, float lo, float hi, unsigned seed);

@@ -85,6 +85,7 @@ class Oracle:
         L.fo_field.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.fo_field.restype = FP
         L.fo_particles_update.argtypes = [G, FP, FP, C.POINTER(ParticleParams), C.c_long] + [FP] * 7
+        L.fo_particle_lines.argtypes = [C.c_long] + [FP] * 5 + [f] * 3 + [FP] * 2
         L.fo_fill_uniform.argtypes = [FP, C.c_long, f, f, C.c_uint]
         L.fo_omp_threads.restype = C.c_int
 
@@ -132,6 +133,12 @@ class Oracle:
 
     def renderSpeed(self, g, u, v, out4, scale):
         self.lib.fo_renderSpeed(C.byref(g), _p(u), _p(v), _p(out4), scale)
+
+    def particle_lines(self, px, py, vx, vy, life, view, scale):
+        n = len(px)
+        xy, alpha = np.empty((n, 4), np.float32), np.empty(n, np.float32)
+        self.lib.fo_particle_lines(n, _p(px), _p(py), _p(vx), _p(vy), _p(life), view[0], view[1], scale, _p(xy), _p(alpha))
+        return xy, alpha
 
     def particles_update(self, g, u, v, pp, arrs):
         n = arrs[0].shape[0]

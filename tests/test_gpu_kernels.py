@@ -457,3 +457,27 @@ def test_advect_fade_equals_advect_then_fade(lib, oracle, W, H):
                             stream()))
     sync()
     assert np.array_equal(host_planes(do, W), e)
+
+
+def test_particle_line_vertices(lib, oracle):
+    """particleVertex (Shaders:446-476) as a compute pass: (pos - vel * scale, pos) in NDC, alpha = life."""
+    import torch
+    n = 10007
+    rng = np.random.default_rng(12)
+    px, py = rng.uniform(-60, 860, n).astype(F), rng.uniform(-60, 660, n).astype(F)
+    vx, vy = rng.uniform(-30, 30, n).astype(F), rng.uniform(-30, 30, n).astype(F)
+    life = rng.uniform(0, 1, n).astype(F)
+    life[::7] = 0.0
+    exy, ealpha = oracle.particle_lines(px, py, vx, vy, life, (800.0, 600.0), 1.5)
+    dev = [torch.from_numpy(a).cuda() for a in (px, py, vx, vy, life)]
+    xy = torch.full((n, 4), float("nan"), dtype=torch.float32, device="cuda")
+    alpha = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+    from gpu_util import stream, sync
+    ok(lib.fs_k_particle_lines(n, *[C.c_void_p(t.data_ptr()) for t in dev], 800.0, 600.0, 1.5,
+                               C.c_void_p(xy.data_ptr()), C.c_void_p(alpha.data_ptr()), stream()))
+    sync()
+    assert np.array_equal(xy.cpu().numpy(), exy) and np.array_equal(alpha.cpu().numpy(), ealpha)
+    # a tracer at rest in the window centre is the degenerate line (0, -0) -> (0, -0)
+    one = oracle.particle_lines(np.array([400.0], F), np.array([300.0], F), np.zeros(1, F), np.zeros(1, F), np.ones(1, F),
+                                (800.0, 600.0), 1.0)
+    assert np.all(one[0] == 0) and one[1][0] == 1.0

@@ -131,3 +131,66 @@ def test_rank_per_process_equals_oracle(tmp_path, oracle_omp, world, name, overl
         if name == "fast_flow_replans" and overlap:
             assert int(d["redo"]) >= 1, d["halos"]
     assert np.abs(vel).max() > 0
+
+
+def _tracer_worker(rank, world, W, H, params, frames, n, outdir):
+    os.environ["FS_RCCL_LIBRARY"] = MOCK
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from fluidsolver_amd.native_slabs import RcclSlab
+    from fluidsolver_amd.script import splat
+    from test_gpu_native_slabs import _tracers
+    s = RcclSlab(W, H, params, device=0, rank=rank, world=world, dist=FileRendezvous(os.path.join(outdir, "id")))
+    try:
+        s.particles_reserve(n, fluidForce=2.0, linkToViscosity=False)
+        s.particles_set(*_tracers(n, W, H))
+        for f in range(frames):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 9 * f + 1, ptr, 2)
+                s.add_force(pos, force, col)
+            s.update()
+        s.sync()
+        np.savez(os.path.join(outdir, "tracers%d.npz" % rank), t=s.particles_get(), received=s.stats["tracers_received"])
+    finally:
+        s.close()
+
+
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/mock_rccl/libmock_rccl.so not built (__graft_entry__.build())")
+@pytest.mark.parametrize("world", [2, 4])
+def test_tracers_rank_per_process_equal_single_gpu(tmp_path, world):
+    """Tracer migration through the RCCL code path (count matrix by all-reduce, payload by send/recv), one
+    process per rank: the union of the ranks' tracers equals the single-GPU tracer set bit for bit."""
+    from fluidsolver_amd import FluidSolver, ParticleSystem
+    from fluidsolver_amd.script import splat
+    from test_gpu_native_slabs import _sorted_columns, _tracers
+    W, H, params, n, frames = 448, 420, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 8), 20000, 5
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tracer_worker, args=(r, world, W, H, params, frames, n, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    s = FluidSolver(W, H, max_particles=n)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    ps = ParticleSystem(s)
+    ps.fluidForce, ps.linkToViscosity = 2.0, False
+    ps.set_arrays(*_tracers(n, W, H))
+    for f in range(frames):
+        for ptr in range(2):
+            pos, force, col = splat(W, H, 9 * f + 1, ptr, 2)
+            s.applyForce(pos, force, col)
+        s.update()
+        ps.update(s, (W, H))
+    s.sync()
+    exp = _sorted_columns(np.stack(ps.get_arrays()))
+    s.close()
+    for p in procs:
+        p.join(150)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung, "ranks hung"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    parts = [np.load(os.path.join(str(tmp_path), "tracers%d.npz" % r)) for r in range(world)]
+    got = _sorted_columns(np.concatenate([d["t"] for d in parts], axis=1))
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    assert sum(int(d["received"]) for d in parts) > 0

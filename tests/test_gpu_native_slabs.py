@@ -214,3 +214,83 @@ def test_rccl_transport_single_rank():
     finally:
         a.close()
         b.close()
+
+
+def _tracers(n, W, H, seed=3):
+    rng = np.random.default_rng(seed)
+    z = np.zeros(n, F)
+    return [rng.uniform(0, W, n).astype(F), rng.uniform(0, H, n).astype(F), z, z.copy(),
+            rng.uniform(0.3, 1.0, n).astype(F), rng.uniform(0.1, 1.0, n).astype(F), z.copy()]
+
+
+def _sorted_columns(a):
+    """[7, n] tracer arrays as a canonically ordered multiset (the slab runtime does not keep an order)."""
+    a = np.asarray(a)
+    return a[:, np.lexsort(a[::-1])]
+
+
+@pytest.mark.parametrize("asynchronous", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_tracers_on_slabs_equal_single_gpu(world, asynchronous):
+    """tracers live on the slab that owns the row their lookup reads and migrate when they
+    cross.  After several frames of a strong flow the union of the slabs' tracers must equal the single-GPU
+    tracer set bit for bit (as a multiset), every tracer must sit on the rank that owns its row, and some must
+    have migrated after the initial distribution."""
+    from fluidsolver_amd import FluidSolver, ParticleSystem
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params, n, frames = 448, 420, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 8), 30000, 6
+    arrs = _tracers(n, W, H)
+    g = LocalGroup(W, H, params, world, device=0, asynchronous=asynchronous)
+    s = FluidSolver(W, H, max_particles=n)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    ps = ParticleSystem(s)
+    ps.fluidForce, ps.linkToViscosity = 2.0, False       # strong coupling so that tracers really travel
+    ps.set_arrays(*arrs)
+    try:
+        for sl in g.slabs:
+            sl.particles_reserve(n, fluidForce=2.0, linkToViscosity=False)
+            sl.particles_set(*arrs)
+        received_after_first = None
+        for f in range(frames):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 9 * f + 1, ptr, 2)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+            ps.update(s, (W, H))
+            if f == 0:
+                received_after_first = sum(sl.stats["tracers_received"] for sl in g.slabs)
+        g.sync()
+        s.sync()
+        parts = [sl.particles_get() for sl in g.slabs]
+        assert sum(p.shape[1] for p in parts) == n
+        got = _sorted_columns(np.concatenate(parts, axis=1))
+        exp = _sorted_columns(np.stack(ps.get_arrays()))
+        assert np.array_equal(got, exp)
+        assert sum(sl.stats["tracers_received"] for sl in g.slabs) > received_after_first, "nothing migrated after frame 0"
+        moved = np.abs(exp[0] - np.sort(arrs[0])).max()
+        assert moved > 0
+    finally:
+        g.close()
+        s.close()
+
+
+def test_tracer_capacity_is_checked():
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params, n = 256, 240, (1.5e-4, 0.0, 0.5, 0.0, 0.002, 4), 4000
+    arrs = _tracers(n, W, H)
+    arrs[1][:] = 5.0                                      # every tracer belongs to rank 0
+    g = LocalGroup(W, H, params, 2, device=0)
+    try:
+        for sl in g.slabs:
+            sl.particles_reserve(n // 2 + 10)
+            sl.particles_set(*arrs)
+        with pytest.raises(L.FluidSolverError) as e:
+            g.update()
+        assert e.value.code == -3 and "capacity" in str(e.value)
+    finally:
+        g.close()

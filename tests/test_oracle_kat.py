@@ -371,3 +371,16 @@ def test_particles_kat(oracle):
     assert nlife[2] == 0.0
     # particle 3: ageDecay = max(0, 1 - 1*3) = 0, momentum -> 1.0; flies off-screen (>W+50)
     assert nvx[3] == F(100.0) and npx[3] == F(163.0) and nlife[3] == 0.0
+
+
+def test_particle_line_vertices_kat(oracle):
+    """particleVertex, Shaders:446-476: a tracer at (600, 150) moving by (+80, -60) per frame in an 800 x 600
+    viewport, scale 1: start = (520, 210) -> NDC (0.3, 0.3) (y flipped), end = (600, 150) -> (0.5, 0.5)."""
+    F = np.float32
+    xy, alpha = oracle.particle_lines(np.array([600.0], F), np.array([150.0], F), np.array([80.0], F), np.array([-60.0], F),
+                                      np.array([0.25], F), (800.0, 600.0), 1.0)
+    assert np.allclose(xy[0], [0.3, 0.3, 0.5, 0.5], atol=1e-6) and alpha[0] == F(0.25)
+    # corners of the viewport are the corners of NDC, y up
+    xy, _ = oracle.particle_lines(np.array([0.0, 800.0], F), np.array([0.0, 600.0], F), np.zeros(2, F), np.zeros(2, F),
+                                  np.ones(2, F), (800.0, 600.0), 1.0)
+    assert np.array_equal(xy[:, 2:], np.array([[-1.0, 1.0], [1.0, -1.0]], F))
