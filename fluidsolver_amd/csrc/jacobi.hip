@@ -36,7 +36,9 @@ struct JacobiArgs {
     const float *div;  // pressure only
     size_t stride;     // floats between planes (plane = blockIdx.z)
     int T;             // sweeps in this launch (>= 1)
-    int HX;            // horizontal halo, multiple of 4, >= T
+    int TE;            // rim of the tile that is not stored: T, or T + 1 with the gradient epilogue
+    int HX;            // horizontal halo, multiple of 4, >= TE
+    float *gu, *gv;    // gradient epilogue (EPI): velocity planes updated in place from the final iterate
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
     int xcd_chunked;   // tile order, see the kernel
@@ -143,7 +145,11 @@ __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
 
 // MINW = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
 // (8 rows, 8 waves) at MINW 4 keeps two 512-thread workgroups per CU, so one can load while the other sweeps.
-template <int OP, int R, int NW, int MINW>
+// EPI (pressure only, last launch of the loop): subtractGradient (Shaders:225-245) from the final iterate while
+// it is still in registers -- the sweeps are bound by VALU issue, so the 16 B/cell of velocity traffic ride along
+// and the separate pass over p, u, v (Solver:544-547) disappears.  The gradient needs the final p of the four
+// neighbours, i.e. one more ring of the tile: the stored region shrinks by TE = T + 1 instead of T.
+template <int OP, int R, int NW, int MINW, bool EPI>
 __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 {
     constexpr int TW = 256;
@@ -172,13 +178,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         }
     }
     const int OW = TW - 2 * A.HX;
-    const int OH = TH - 2 * A.T;
+    const int OH = TH - 2 * A.TE;
     // Tile order.  Plain blockIdx by default; for a pressure loop whose three planes fit the Infinity Cache
     // each XCD takes one contiguous chunk of the grid, so the overlapping tile rims hit in its L2 (3072^2:
     // 143 -> 128 us per 40 sweeps; at 16384^2, HBM-bound, the same remap costs 4 %: eight distant streams).
     const uint2 tile = A.xcd_chunked ? xcd_tile_chunked() : make_uint2(blockIdx.x, blockIdx.y);
     const int x0 = tile.x * OW - A.HX;                   // tile column 0 (global), multiple of 4
-    const int ry0 = A.yb + tile.y * OH - A.T;            // tile row 0 (global)
+    const int ry0 = A.yb + tile.y * OH - A.TE;           // tile row 0 (global)
     const int gx = x0 + 4 * lane;                        // this lane's first column
     const int wy0 = ry0 + wave * R;                      // this wave's first row
     const size_t plane = (size_t)blockIdx.z * A.stride;
@@ -222,6 +228,41 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 
     // store the exact inner region
     const bool col_out = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
+    if (EPI) {
+        // final iterate of the rows above / below this wave's strip: one more round of the edge-row exchange
+        const int buf = A.T & 1;
+        const int wup = wave > 0 ? wave - 1 : 0, wdn = wave < NW - 1 ? wave + 1 : NW - 1;
+        xch[buf][wave][0][lane] = f4_of(p[0]);
+        xch[buf][wave][1][lane] = f4_of(p[R - 1]);
+        __syncthreads();
+        Row prev = row_of(xch[buf][wup][1][lane]);
+        const Row below = row_of(xch[buf][wdn][0][lane]);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const Row c = p[i];
+            const Row nx = (i < R - 1) ? p[i + 1] : below;
+            const float lx = from_lane_below(c.b.y);   // column 4l-1
+            const float rw = from_lane_above(c.a.x);   // column 4l+4
+            const int ty = wave * R + i;
+            const int y = wy0 + i;
+            if (col_out && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) {
+                const size_t o = row_off(g, y) + gx;
+                st4(out + o, f4_of(c));
+                if (!((rowfixed >> i) & 1u)) {         // boundary rows keep their velocity (Shaders:230-233)
+                    float4 uu = ld4(A.gu + o), vv = ld4(A.gv + o);
+                    // vel.x -= 0.5 (p_r - p_l); vel.y -= 0.5 (p_b - p_t)                Shaders:240-243
+                    if (!fx0) { uu.x = uu.x - 0.5f * (c.a.y - lx);    vv.x = vv.x - 0.5f * (nx.a.x - prev.a.x); }
+                    if (!fx1) { uu.y = uu.y - 0.5f * (c.b.x - c.a.x); vv.y = vv.y - 0.5f * (nx.a.y - prev.a.y); }
+                    if (!fx2) { uu.z = uu.z - 0.5f * (c.b.y - c.a.y); vv.z = vv.z - 0.5f * (nx.b.x - prev.b.x); }
+                    if (!fx3) { uu.w = uu.w - 0.5f * (rw - c.b.x);    vv.w = vv.w - 0.5f * (nx.b.y - prev.b.y); }
+                    st4(A.gu + o, uu);
+                    st4(A.gv + o, vv);
+                }
+            }
+            prev = c;
+        }
+        return;
+    }
     if (col_out) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -245,17 +286,20 @@ template <int OP, int R, int NW, int MINW>
 static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, hipStream_t stream)
 {
     JacobiArgs A = A0;
-    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * A.T;
+    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * A.TE;
     if (OH < 1) { set_error("jacobi: block depth %d too deep for a %d-row tile", A.T, NW * R); return FS_ERR_INVALID; }
     dim3 grid((g->width + OW - 1) / OW, (A.ye - A.yb + OH - 1) / OH, nplanes);
-    hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW>), grid, dim3(NW * 64), 0, stream, A);
+    if (OP == OP_PRESSURE && A.gu)
+        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, OP == OP_PRESSURE>), grid, dim3(NW * 64), 0, stream, A);
+    else
+        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, false>), grid, dim3(NW * 64), 0, stream, A);
     FS_LAUNCH_CHECK("k_jacobi_block");
     return FS_OK;
 }
 
 template <int OP>
 static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
-                        int nplanes, size_t stride, int T, float a, float den, hipStream_t stream)
+                        int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream)
 {
     JacobiArgs A;
     A.g = make_gk(g);
@@ -266,7 +310,10 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.div = div;
     A.stride = stride;
     A.T = T;
-    A.HX = (T + 3) & ~3;
+    A.gu = gu;
+    A.gv = gv;
+    A.TE = T + (gu ? 1 : 0);
+    A.HX = (A.TE + 3) & ~3;
     A.a = a;
     A.den = den;
     A.rden = 1.0 / (double)den;
@@ -288,12 +335,15 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
 
 // n sweeps ping-ponging a -> b -> a ...; launch j must leave rows [yb-rem, ye+rem) valid,
 // rem = sweeps still to come, clipped to the domain.
+// gu/gv != nullptr (pressure): the last launch also subtracts the gradient of the final iterate from them
 template <int OP>
 static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
-                      size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream)
+                      size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
+                      float *gu = nullptr, float *gv = nullptr)
 {
-    const int need_lo = g->yb - n > 0 ? g->yb - n : 0;
-    const int need_hi = g->ye + n < g->height ? g->ye + n : g->height;
+    const int ex = gu ? 1 : 0;   // the gradient epilogue reads one more ring of the final iterate
+    const int need_lo = g->yb - n - ex > 0 ? g->yb - n - ex : 0;
+    const int need_hi = g->ye + n + ex < g->height ? g->ye + n + ex : g->height;
     if (need_lo < g->y0 || need_hi > g->y0 + g->rows) {
         set_error("jacobi: %d sweeps on rows [%d,%d) need rows [%d,%d) but the buffer holds [%d,%d)", n, g->yb,
                   g->ye, need_lo, need_hi, g->y0, g->y0 + g->rows);
@@ -307,10 +357,13 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
     while (rem > 0) {
         const int T = rem < maxT ? rem : maxT;
         rem -= T;
-        int yb = g->yb - rem, ye = g->ye + rem;
+        const int more = rem > 0 ? rem + ex : 0;
+        int yb = g->yb - more, ye = g->ye + more;
         if (yb < 0) yb = 0;
         if (ye > g->height) ye = g->height;
-        int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden, stream);
+        const bool last = rem == 0;
+        int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
+                                  last ? gu : nullptr, last ? gv : nullptr, stream);
         if (rc) return rc;
         float *t = src; src = dst; dst = t;
         src_zero = false;
@@ -405,6 +458,19 @@ int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *p
         return FS_OK;
     }
     return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream);
+}
+
+int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero,
+                                  float *u, float *v, int *result_in_b, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(div && pa && pb && pa != pb && u && v, "bad pointers");
+    REQUIRE(n >= 1, "needs at least one sweep (use fs_k_subtractGradient after fs_k_clear otherwise)");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb) return FS_OK;
+    // (the launches before the last leave one more row of p exact on each side: the gradient reads it)
+    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v);
 }
 
 int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)

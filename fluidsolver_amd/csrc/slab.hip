@@ -143,7 +143,7 @@ struct Planner {
     // previous iterate on +- (d+1), i.e. consumes one row of ghost depth.  The sweeps run in as few
     // temporally blocked chunks as the available depth allows; ghosts are re-exchanged only when the
     // depth is used up.
-    void sweeps(bool pressure, int fi, int N, int need_out)
+    void sweeps(bool pressure, int fi, int N, int need_out, bool with_gradient = false)
     {
         Field &F = c->f[fi];
         int remaining = N;
@@ -176,10 +176,17 @@ struct Planner {
                 const int pz = c->p_zero ? 1 : 0;
                 c->p_zero = false;
                 const float *div = c->f[F_DIV].p();
-                compute("pressure_n", g, n, [=]() {                                   // Solver:533-541
-                    int ib = 0;
-                    return fs_k_pressureSolve_n(&g, div, src, dst, n, pz, &ib, st);
-                });
+                float *u = c->f[F_VEL].p(), *v = u + c->plane;
+                if (with_gradient)
+                    compute("pressure_n_gradient", g, n, [=]() {                      // Solver:533-547
+                        int ib = 0;
+                        return fs_k_pressureSolve_n_gradient(&g, div, src, dst, n, pz, u, v, &ib, st);
+                    });
+                else
+                    compute("pressure_n", g, n, [=]() {                               // Solver:533-541
+                        int ib = 0;
+                        return fs_k_pressureSolve_n(&g, div, src, dst, n, pz, &ib, st);
+                    });
             } else {
                 const float coeff = fi == F_VEL ? c->params.viscosity : c->params.diffusion;
                 const float dt = c->params.deltaTime;
@@ -268,8 +275,14 @@ struct Planner {
         if (multi) c->f[F_DIV].valid = dd;
         c->p_zero = true;                                                             // clear folded in, :528-530
         c->f[F_P].valid = kInf;
+        // one GPU: the gradient is subtracted by the last pressure launch, from registers (FS_OPT_FUSE).  Pays while
+        // the loop is VALU-bound, i.e. while its planes sit in the Infinity Cache (-10 us of 597 at 3072^2); at
+        // 16384^2 the loop streams from HBM, the extra 16 B/cell no longer ride for free and it costs 0.3 %
+        // (profiles/r01_h_ab_fuse*.log), so the separate pass is kept there.
+        const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
+        const bool grad_fused = !multi && (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0;
         if (N > 0) {
-            sweeps(true, F_P, N, need_p);                                             // :533-541
+            sweeps(true, F_P, N, need_p, grad_fused);                                 // :533-541 (+ :544-547)
         } else {
             const fs_grid g = grid_of(c, G);
             float *pp = c->f[F_P].p();
@@ -280,7 +293,9 @@ struct Planner {
         {
             const fs_grid g = grid_of(c, 0);
             float *u = V.p(), *v = u + plane, *pp = c->f[F_P].p();
-            if (!multi) {
+            if (grad_fused) {
+                // done
+            } else if (!multi) {
                 compute("subtractGradient", g, 0, [=]() { return fs_k_subtractGradient(&g, pp, u, v, st); }); // :544-547
             } else {
                 // ... and, in the same pass, the CFL bound of the backtrace: max |v_y| over the owned rows
@@ -309,6 +324,7 @@ struct Planner {
         const int ddn = (p.diffusion > 0.0f && N > 0) ? N : 0;
         hipStream_t st = c->stream;
         const size_t plane = c->plane;
+        const bool fade_fused = c->fuse == 1 || c->fuse == 2;
         // overlap: the advected velocity is also computed on the ghost rows the next frame's stencil
         // chain consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
         const int adv = (multi && c->overlap) ? std::max(0, std::min(chain_needs().v0, G - h)) : 0;
@@ -319,7 +335,7 @@ struct Planner {
             // interior rows: no tap of their backtrace leaves the owned rows            :550-558, :577-591
             advect_rows(F_VEL, false, i0, i1);
             c->f[F_VEL].cur ^= 1;
-            advect_rows(F_DYE, c->fuse != 0, i0, i1);
+            advect_rows(F_DYE, fade_fused, i0, i1);
             c->f[F_VEL].cur ^= 1;
             join(SLOT_VEL);
             advect_rows(F_VEL, false, c->r0 - adv, i0);
@@ -327,8 +343,8 @@ struct Planner {
             c->f[F_VEL].cur ^= 1;                                                     // :558
             c->f[F_VEL].valid = adv;
             join(SLOT_DYE);
-            advect_rows(F_DYE, c->fuse != 0, c->r0, i0);
-            advect_rows(F_DYE, c->fuse != 0, i1, c->r1);
+            advect_rows(F_DYE, fade_fused, c->r0, i0);
+            advect_rows(F_DYE, fade_fused, i1, c->r1);
             c->f[F_DYE].cur ^= 1;                                                     // :584
         } else {
             if (multi) {
@@ -340,9 +356,9 @@ struct Planner {
                 sweeps(false, F_DYE, N, h);
                 need(F_DYE, h);
             }
-            advect(F_DYE, c->fuse != 0);                                              // :577-584 (+ :587-591 when fused)
+            advect(F_DYE, fade_fused);                                              // :577-584 (+ :587-591 when fused)
         }
-        if (!c->fuse) {
+        if (!fade_fused) {
             const fs_grid g = grid_of(c, 0);
             float *d = c->f[F_DYE].p();
             const float fr = p.fadeSpeed;
@@ -717,6 +733,7 @@ int tracer_phase(fs_ctx *c, int phase)
             at += c->tr_recv_cnt[q];
             moved += c->tr_recv_cnt[q];
         }
+        FS_HIP(hipDeviceSynchronize());   // device-to-device copies may return before they are done
     }
     for (int f = 0; f < 7; ++f) std::swap(c->part[f], c->part_t[f]);
     c->n_particles = at;

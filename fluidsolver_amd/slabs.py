@@ -89,6 +89,13 @@ class HipBackend:
                                               1 if p_is_zero else 0, C.byref(in_b), self._s()))
         return bool(in_b.value)
 
+    def pressure_n_gradient(self, g, div, pa, pb, n, p_is_zero, vel):
+        in_b = C.c_int(0)
+        L.check(self.lib.fs_k_pressureSolve_n_gradient(C.byref(g), self._p(div), self._p(pa), self._p(pb), n,
+                                                       1 if p_is_zero else 0, self._p(vel, 0), self._p(vel, 1),
+                                                       C.byref(in_b), self._s()))
+        return bool(in_b.value)
+
     def clear(self, g, t):
         L.check(self.lib.fs_k_clear(C.byref(g), self._p(t), t.shape[0], t.stride(0), self._s()))
 
@@ -256,7 +263,7 @@ class SlabSolver:
             self.valid[name] = d
 
     # ---- Jacobi loops with lazy re-exchange ----------------------------------------------------
-    def _sweeps(self, kind, name, N, need_out):
+    def _sweeps(self, kind, name, N, need_out, with_gradient=False):
         """N sweeps on field `name` (ping-pong with name_t).  One sweep computed on the owned rows +- d
         reads the previous iterate on +- (d+1), i.e. consumes one row of ghost depth.  The sweeps run in
         as few temporally blocked chunks as the available depth allows; ghosts are re-exchanged only
@@ -287,7 +294,10 @@ class SlabSolver:
                 assert n >= 1 and out_depth >= 0 and out_depth + n <= self.G, (n, out_depth, self.G)
             g = self.grid(out_depth)
             src, dst = self.f[name], self.f[name + "_t"]
-            if kind == "pressure":
+            if kind == "pressure" and with_gradient:
+                in_b = self.be.pressure_n_gradient(g, self.f["div"], src, dst, n, self._p_zero, self.f["vel"])
+                self._p_zero = False
+            elif kind == "pressure":
                 in_b = self.be.pressure_n(g, self.f["div"], src, dst, n, self._p_zero)
                 self._p_zero = False
             else:
@@ -359,14 +369,20 @@ class SlabSolver:
             V["div"] = dd
         self._p_zero = True                                                    # clear folded in, :528-530
         V["p"] = INF
+        # one GPU: the gradient is subtracted by the last pressure launch, from registers
+        # (while the loop's planes sit in the Infinity Cache; beyond that the separate pass is faster)
+        cache_resident = 3.0 * self.pitch * self.H * 4 < 192.0 * 1024 * 1024
+        grad_fused = not multi and N > 0 and cache_resident and hasattr(self.be, "pressure_n_gradient")
         if N > 0:
-            self._sweeps("pressure", "p", N, need_p)                           # :533-541
+            self._sweeps("pressure", "p", N, need_p, grad_fused)               # :533-541 (+ :544-547)
         else:
             self.be.clear(self.grid(self.G), self.f["p"])
         self._need("p", 1)
         # ---- advection: halo from the CFL bound of the backtrace ----
         h = 0
-        if not multi:
+        if grad_fused:
+            pass
+        elif not multi:
             self.be.subtractGradient(self.grid(0), self.f["p"], self.f["vel"])     # :544-547
         else:
             # ... with max |v_y| of the owned rows in the same pass, then max over ranks

@@ -123,6 +123,12 @@ int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float
 int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *pb, int n,
                          int p_is_zero, int *result_in_b, void *stream);
 
+/* fs_k_pressureSolve_n followed by fs_k_subtractGradient (Solver:533-547) with the gradient subtracted by the
+ * LAST launch of the loop from the final iterate while it is in registers: same bits in p, u, v as the two
+ * calls, one pass over p, u, v less.  n >= 1; rows [yb-n-1, ye+n+1) of div must be valid (clipped to the domain). */
+int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa, float *pb, int n,
+                                  int p_is_zero, float *u, float *v, int *result_in_b, void *stream);
+
 /* replaces kernel subtractGradient, Shaders:225-245 (velocity in place) */
 int fs_k_subtractGradient(const fs_grid *g, const float *p, float *u, float *v, void *stream);
 
@@ -230,7 +236,8 @@ enum { FS_FIELD_VELOCITY = 0, FS_FIELD_DENSITY = 1, FS_FIELD_PRESSURE = 2,
 enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph */
        FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), both loops */
        FS_OPT_WITH_PARTICLES = 2, /* 1: fs_step also runs the tracer update (default 0) */
-       FS_OPT_FUSE = 4,
+       FS_OPT_FUSE = 4,           /* fs_step fusions, same bits either way: 1 (default) = fadeDensity into the dye advection AND
+                                     subtractGradient into the last pressure launch; 2 = the first only; 3 = the second only; 0 = none */
        FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* fs_config_set/get only: depth of the pressure loop, default 10 */
        FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */           /* 1 (default): fs_step fuses fadeDensity into the dye advection pass */
        FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident

@@ -79,6 +79,11 @@ class OracleBackend:
             pa.zero_()
         return self._sweeps(g, lambda og, s, d: self.o.pressureSolve(og, dv, s, d), pa, pb, n)
 
+    def pressure_n_gradient(self, g, div, pa, pb, n, p_is_zero, vel):
+        in_b = self.pressure_n(g, div, pa, pb, n, p_is_zero)
+        self.subtractGradient(g, pb if in_b else pa, vel)
+        return in_b
+
     def divergence(self, g, vel, div):
         W = g.width
         v, o = self._dense(vel, W), self._dense(div, W)

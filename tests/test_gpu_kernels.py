@@ -481,3 +481,61 @@ def test_particle_line_vertices(lib, oracle):
     one = oracle.particle_lines(np.array([400.0], F), np.array([300.0], F), np.zeros(1, F), np.zeros(1, F), np.ones(1, F),
                                 (800.0, 600.0), 1.0)
     assert np.all(one[0] == 0) and one[1][0] == 1.0
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(600, 150), (1000, 333)])
+@pytest.mark.parametrize("n", [1, 4, 10, 13, 27])
+def test_pressure_loop_with_gradient_epilogue(lib, oracle, W, H, n):
+    """fs_k_pressureSolve_n_gradient == n pressureSolve sweeps + subtractGradient (Solver:533-547), bit for bit in
+    p, u and v: the gradient is taken from the last launch's registers, one ring deeper in the tile."""
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    div, vel = rnd((H, W), 31, -1, 1), rnd((2, H, W), 32, -2, 2)
+    og = full_grid(W, H)
+    a, b = np.zeros((H, W), F), np.zeros((H, W), F)
+    for _ in range(n):
+        oracle.pressureSolve(og, div, a, b)
+        a, b = b, a
+    e = vel.copy()
+    oracle.subtractGradient(og, a, e[0], e[1])
+    g = grid(W, H)
+    dd, dv = dev_planes(div), dev_planes(vel)
+    pa, pb = dev_planes(rnd((H, W), 33)), dev_planes(np.zeros((H, W), F))   # pa holds garbage: p_is_zero ignores it
+    in_b = C.c_int(-1)
+    ok(lib.fs_k_pressureSolve_n_gradient(C.byref(g), ptr(dd), ptr(pa), ptr(pb), n, 1, ptr(dv, 0), ptr(dv, 1),
+                                         C.byref(in_b), stream()))
+    sync()
+    assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
+    assert np.array_equal(host_planes(dv, W), e)
+
+
+def test_pressure_gradient_epilogue_on_a_row_range(lib, oracle):
+    """The same on a slab-like buffer: rows [40, 200) of a 260-row domain held with 45 ghost rows, computing rows
+    [60, 180): needs n + 1 rows of div around them, touches no velocity row outside [60, 180)."""
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    W, H, n = 333, 260, 12
+    div, vel = rnd((H, W), 41, -1, 1), rnd((2, H, W), 42, -2, 2)
+    og = full_grid(W, H)
+    a, b = np.zeros((H, W), F), np.zeros((H, W), F)
+    for _ in range(n):
+        oracle.pressureSolve(og, div, a, b)
+        a, b = b, a
+    e = vel.copy()
+    oracle.subtractGradient(og, a, e[0], e[1])
+    y0, rows, yb, ye = 40, 160, 60, 180
+    g = grid(W, H, y0=y0, rows=rows, yb=yb, ye=ye)
+    dd, dv = dev_planes(div[y0:y0 + rows]), dev_planes(vel[:, y0:y0 + rows])
+    pa, pb = dev_planes(np.zeros((rows, W), F)), dev_planes(np.zeros((rows, W), F))
+    in_b = C.c_int(-1)
+    ok(lib.fs_k_pressureSolve_n_gradient(C.byref(g), ptr(dd), ptr(pa), ptr(pb), n, 1, ptr(dv, 0), ptr(dv, 1),
+                                         C.byref(in_b), stream()))
+    sync()
+    got = host_planes(dv, W)
+    assert np.array_equal(got[:, yb - y0:ye - y0], e[:, yb:ye])
+    assert np.array_equal(got[:, :yb - y0], vel[:, y0:yb]) and np.array_equal(got[:, ye - y0:], vel[:, ye:y0 + rows])
+    assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0][yb - y0:ye - y0], a[yb:ye])
+    # one ghost row too few is refused, not computed wrongly
+    g2 = grid(W, H, y0=y0, rows=rows, yb=y0 + n, ye=ye)
+    assert lib.fs_k_pressureSolve_n_gradient(C.byref(g2), ptr(dd), ptr(pa), ptr(pb), n, 1, ptr(dv, 0), ptr(dv, 1),
+                                             C.byref(in_b), stream()) == -1

@@ -117,6 +117,33 @@ def test_frames_match_oracle(oracle, W, H, params):
     s.sync()
 
 
+def test_no_drift_over_100_frames(oracle_omp):
+    """north_star's "bounded drift over 100 frames": 100 scripted full-strength frames of BASELINE config 1
+    (256 x 256, N = 20, defaults of Solver:139-202) plus vorticity confinement.  The stated tolerance is a max
+    relative error of 1e-5 per step; the build is held to zero: velocity, dye and pressure are compared with
+    == after frames 1, 10 and 100, so the drift is exactly 0."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 256
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 20)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(100):
+        pos, force, col = splat(W, H, f)
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, p.deltaTime)
+        s.update()
+        o.update(p)
+        if f in (0, 9, 99):
+            for fid, oid in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+                got, exp = s.read_field(fid), o.field(oid)
+                assert np.array_equal(got, exp), (f, fid, float(np.abs(got - exp).max()))
+    assert np.abs(o.field(VELOCITY)).max() > 1.0 and np.isfinite(o.field(DENSITY)).all()
+    s.sync()
+
+
 def test_update_boundary_invariants():
     from fluidsolver_amd import lib as L
     W, H = 96, 72
