@@ -39,6 +39,8 @@ struct JacobiArgs {
     int TE;            // rim of the tile that is not stored: T, or T + 1 with the gradient epilogue
     int HX;            // horizontal halo, multiple of 4, >= TE
     float *gu, *gv;    // gradient epilogue (EPI): velocity planes updated in place from the final iterate
+    const float *du, *dv;   // divergence prologue (PRO): velocity planes the divergence is computed from ...
+    float *div_out;         // ... and the plane it is stored to (for the later launches of the loop)
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
     int xcd_chunked;   // tile order, see the kernel
@@ -149,7 +151,11 @@ __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
 // it is still in registers -- the sweeps are bound by VALU issue, so the 16 B/cell of velocity traffic ride along
 // and the separate pass over p, u, v (Solver:544-547) disappears.  The gradient needs the final p of the four
 // neighbours, i.e. one more ring of the tile: the stored region shrinks by TE = T + 1 instead of T.
-template <int OP, int R, int NW, int MINW, bool EPI>
+// PRO (pressure only, first launch of the loop, p = 0): divergence (Shaders:162-181) computed from u, v for the
+// tile instead of loaded, and stored once per cell for the later launches: the separate divergence pass
+// (Solver:522-525) disappears.  The outermost ring of the tile gets a wrong divergence (its neighbours lie outside
+// the tile); that ring is invalid after the first sweep anyway and is never stored.
+template <int OP, int R, int NW, int MINW, bool EPI, bool PRO>
 __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 {
     constexpr int TW = 256;
@@ -214,10 +220,46 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         if (row_in_buf && col_in_buf && !(A.stagger_mode & 32)) {
             const size_t o = row_off(g, y) + gx;
             if (in) pv = ld4(in + o);
-            if (OP == OP_PRESSURE) dv = ld4(A.div + o);
+            if (OP == OP_PRESSURE && !PRO) dv = ld4(A.div + o);
         }
         p[i] = row_of(pv);
         d[i] = row_of(dv);
+    }
+    if (PRO) {
+        // v of the rows above / below this wave's strip through the edge-row exchange (buffer 1: the sweeps start
+        // with buffer 0), u's left / right neighbours by DPP
+        const int wup = wave > 0 ? wave - 1 : 0, wdn = wave < NW - 1 ? wave + 1 : NW - 1;
+        float4 vr[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int y = wy0 + i;
+            const bool ok = y >= g.y0 && y < g.y0 + g.rows && col_in_buf;
+            vr[i] = ok ? ld4(A.dv + row_off(g, y) + gx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        xch[1][wave][0][lane] = vr[0];
+        xch[1][wave][1][lane] = vr[R - 1];
+        __syncthreads();
+        float4 vt = xch[1][wup][1][lane];
+        const float4 vlast = xch[1][wdn][0][lane];
+        const bool col_st = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int y = wy0 + i;
+            const int ty = wave * R + i;
+            const bool ok = y >= g.y0 && y < g.y0 + g.rows && col_in_buf;
+            const float4 uc = ok ? ld4(A.du + row_off(g, y) + gx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 vb = (i < R - 1) ? vr[i + 1] : vlast;
+            const float ul = from_lane_below(uc.w), ur = from_lane_above(uc.x);
+            const bool rf = (rowfixed >> i) & 1u;
+            float4 dv;   // -0.5 ((u_r - u_l) + (v_b - v_t)); boundary 0                  Shaders:172-180
+            dv.x = (rf || fx0) ? 0.0f : -0.5f * ((uc.y - ul) + (vb.x - vt.x));
+            dv.y = (rf || fx1) ? 0.0f : -0.5f * ((uc.z - uc.x) + (vb.y - vt.y));
+            dv.z = (rf || fx2) ? 0.0f : -0.5f * ((uc.w - uc.y) + (vb.z - vt.z));
+            dv.w = (rf || fx3) ? 0.0f : -0.5f * ((ur - uc.z) + (vb.w - vt.w));
+            d[i] = row_of(dv);
+            if (col_st && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) st4(A.div_out + row_off(g, y) + gx, dv);
+            vt = vr[i];
+        }
     }
 
     const int Trun = (A.stagger_mode & 16) ? 0 : A.T;
@@ -289,17 +331,22 @@ static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, h
     const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * A.TE;
     if (OH < 1) { set_error("jacobi: block depth %d too deep for a %d-row tile", A.T, NW * R); return FS_ERR_INVALID; }
     dim3 grid((g->width + OW - 1) / OW, (A.ye - A.yb + OH - 1) / OH, nplanes);
-    if (OP == OP_PRESSURE && A.gu)
-        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, OP == OP_PRESSURE>), grid, dim3(NW * 64), 0, stream, A);
+    constexpr bool PR = OP == OP_PRESSURE;
+    if (PR && A.gu && A.du) { set_error("jacobi: divergence prologue and gradient epilogue cannot share a launch"); return FS_ERR_INVALID; }
+    if (PR && A.gu)
+        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, PR, false>), grid, dim3(NW * 64), 0, stream, A);
+    else if (PR && A.du)
+        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, false, PR>), grid, dim3(NW * 64), 0, stream, A);
     else
-        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, false>), grid, dim3(NW * 64), 0, stream, A);
+        hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, false, false>), grid, dim3(NW * 64), 0, stream, A);
     FS_LAUNCH_CHECK("k_jacobi_block");
     return FS_OK;
 }
 
 template <int OP>
 static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
-                        int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream)
+                        int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream,
+                        const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr)
 {
     JacobiArgs A;
     A.g = make_gk(g);
@@ -312,6 +359,9 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.T = T;
     A.gu = gu;
     A.gv = gv;
+    A.du = du;
+    A.dv = dv;
+    A.div_out = div_out;
     A.TE = T + (gu ? 1 : 0);
     A.HX = (A.TE + 3) & ~3;
     A.a = a;
@@ -339,7 +389,7 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
 template <int OP>
 static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
                       size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
-                      float *gu = nullptr, float *gv = nullptr)
+                      float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr)
 {
     const int ex = gu ? 1 : 0;   // the gradient epilogue reads one more ring of the final iterate
     const int need_lo = g->yb - n - ex > 0 ? g->yb - n - ex : 0;
@@ -361,9 +411,13 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
         int yb = g->yb - more, ye = g->ye + more;
         if (yb < 0) yb = 0;
         if (ye > g->height) ye = g->height;
-        const bool last = rem == 0;
+        const bool last = rem == 0, first = launches == 0;
+        // first launch of a projection: the divergence is computed from gu/gv (still untouched: the epilogue only
+        // runs in the last launch) and stored to div_out for the launches that follow
+        const bool pro = div_prologue && first && !last;
         int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
-                                  last ? gu : nullptr, last ? gv : nullptr, stream);
+                                  last ? gu : nullptr, last ? gv : nullptr, stream, pro ? gu : nullptr, pro ? gv : nullptr,
+                                  pro ? div_out : nullptr);
         if (rc) return rc;
         float *t = src; src = dst; dst = t;
         src_zero = false;
@@ -471,6 +525,23 @@ int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa,
     if (g->ye <= g->yb) return FS_OK;
     // (the launches before the last leave one more row of p exact on each side: the gradient reads it)
     return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v);
+}
+
+int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, int *result_in_b,
+                   void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE(u && v && div && pa && pb && pa != pb, "bad pointers");
+    REQUIRE(n >= 1, "needs at least one sweep");
+    REQUIRE(g->yb == 0 && g->ye == g->height && g->y0 == 0 && g->rows == g->height, "the whole grid on one GPU only");
+    if (result_in_b) *result_in_b = 0;
+    if (jacobi_launch_count(OP_PRESSURE, n) < 2) {
+        // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads)
+        rc = fs_k_divergence(g, u, v, div, stream);
+        if (rc) return rc;
+    }
+    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div);
 }
 
 int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)

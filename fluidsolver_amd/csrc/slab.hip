@@ -177,11 +177,13 @@ struct Planner {
                 c->p_zero = false;
                 const float *div = c->f[F_DIV].p();
                 float *u = c->f[F_VEL].p(), *v = u + c->plane;
-                if (with_gradient)
-                    compute("pressure_n_gradient", g, n, [=]() {                      // Solver:533-547
+                if (with_gradient) {
+                    float *dw = c->f[F_DIV].p();
+                    compute("project_n", g, n, [=]() {                                // Solver:522-547
                         int ib = 0;
-                        return fs_k_pressureSolve_n_gradient(&g, div, src, dst, n, pz, u, v, &ib, st);
+                        return fs_k_project_n(&g, u, v, dw, src, dst, n, &ib, st);
                     });
+                }
                 else
                     compute("pressure_n", g, n, [=]() {                               // Solver:533-541
                         int ib = 0;
@@ -266,8 +268,10 @@ struct Planner {
             sweeps(false, F_VEL, N, need_v2);
         }
         need(F_VEL, need_v2);
+        const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
+        const bool project_fused = !multi && (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0;
         const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
-        {
+        if (!project_fused) {
             const fs_grid g = grid_of(c, dd);
             float *u = V.p(), *v = u + plane, *d = c->f[F_DIV].p();
             compute("divergence", g, 0, [=]() { return fs_k_divergence(&g, u, v, d, st); });              // :522-525
@@ -275,12 +279,11 @@ struct Planner {
         if (multi) c->f[F_DIV].valid = dd;
         c->p_zero = true;                                                             // clear folded in, :528-530
         c->f[F_P].valid = kInf;
-        // one GPU: the gradient is subtracted by the last pressure launch, from registers (FS_OPT_FUSE).  Pays while
+        // one GPU: the divergence is computed by the first pressure launch and the gradient is subtracted by the last pressure launch, from registers (FS_OPT_FUSE).  Pays while
         // the loop is VALU-bound, i.e. while its planes sit in the Infinity Cache (-10 us of 597 at 3072^2); at
         // 16384^2 the loop streams from HBM, the extra 16 B/cell no longer ride for free and it costs 0.3 %
         // (profiles/r01_h_ab_fuse*.log), so the separate pass is kept there.
-        const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
-        const bool grad_fused = !multi && (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0;
+        const bool grad_fused = project_fused;
         if (N > 0) {
             sweeps(true, F_P, N, need_p, grad_fused);                                 // :533-541 (+ :544-547)
         } else {

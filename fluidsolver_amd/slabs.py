@@ -89,11 +89,10 @@ class HipBackend:
                                               1 if p_is_zero else 0, C.byref(in_b), self._s()))
         return bool(in_b.value)
 
-    def pressure_n_gradient(self, g, div, pa, pb, n, p_is_zero, vel):
+    def project_n(self, g, vel, div, pa, pb, n):
         in_b = C.c_int(0)
-        L.check(self.lib.fs_k_pressureSolve_n_gradient(C.byref(g), self._p(div), self._p(pa), self._p(pb), n,
-                                                       1 if p_is_zero else 0, self._p(vel, 0), self._p(vel, 1),
-                                                       C.byref(in_b), self._s()))
+        L.check(self.lib.fs_k_project_n(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(div), self._p(pa),
+                                        self._p(pb), n, C.byref(in_b), self._s()))
         return bool(in_b.value)
 
     def clear(self, g, t):
@@ -295,7 +294,7 @@ class SlabSolver:
             g = self.grid(out_depth)
             src, dst = self.f[name], self.f[name + "_t"]
             if kind == "pressure" and with_gradient:
-                in_b = self.be.pressure_n_gradient(g, self.f["div"], src, dst, n, self._p_zero, self.f["vel"])
+                in_b = self.be.project_n(g, self.f["vel"], self.f["div"], src, dst, n)     # :522-547 in one loop
                 self._p_zero = False
             elif kind == "pressure":
                 in_b = self.be.pressure_n(g, self.f["div"], src, dst, n, self._p_zero)
@@ -363,16 +362,17 @@ class SlabSolver:
             self._need("vel", need_v1)
             self._sweeps("diffuse", "vel", N, need_v2)
         self._need("vel", need_v2)
+        # one GPU: the divergence is computed by the first pressure launch and the gradient subtracted by the last,
+        # from registers (while the loop's planes sit in the Infinity Cache; beyond that separate passes are faster)
+        cache_resident = 3.0 * self.pitch * self.H * 4 < 192.0 * 1024 * 1024
+        grad_fused = not multi and N > 0 and cache_resident and hasattr(self.be, "project_n")
         dd = min(need_div, eff("vel") - 1) if multi else 0
-        self.be.divergence(self.grid(dd), self.f["vel"], self.f["div"])        # :522-525
+        if not grad_fused:
+            self.be.divergence(self.grid(dd), self.f["vel"], self.f["div"])    # :522-525
         if multi:
             V["div"] = dd
         self._p_zero = True                                                    # clear folded in, :528-530
         V["p"] = INF
-        # one GPU: the gradient is subtracted by the last pressure launch, from registers
-        # (while the loop's planes sit in the Infinity Cache; beyond that the separate pass is faster)
-        cache_resident = 3.0 * self.pitch * self.H * 4 < 192.0 * 1024 * 1024
-        grad_fused = not multi and N > 0 and cache_resident and hasattr(self.be, "pressure_n_gradient")
         if N > 0:
             self._sweeps("pressure", "p", N, need_p, grad_fused)               # :533-541 (+ :544-547)
         else:

@@ -79,8 +79,9 @@ class OracleBackend:
             pa.zero_()
         return self._sweeps(g, lambda og, s, d: self.o.pressureSolve(og, dv, s, d), pa, pb, n)
 
-    def pressure_n_gradient(self, g, div, pa, pb, n, p_is_zero, vel):
-        in_b = self.pressure_n(g, div, pa, pb, n, p_is_zero)
+    def project_n(self, g, vel, div, pa, pb, n):
+        self.divergence(g, vel, div)
+        in_b = self.pressure_n(g, div, pa, pb, n, True)
         self.subtractGradient(g, pb if in_b else pa, vel)
         return in_b
 

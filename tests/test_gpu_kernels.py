@@ -539,3 +539,31 @@ def test_pressure_gradient_epilogue_on_a_row_range(lib, oracle):
     g2 = grid(W, H, y0=y0, rows=rows, yb=y0 + n, ye=ye)
     assert lib.fs_k_pressureSolve_n_gradient(C.byref(g2), ptr(dd), ptr(pa), ptr(pb), n, 1, ptr(dv, 0), ptr(dv, 1),
                                              C.byref(in_b), stream()) == -1
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(600, 150), (1000, 333)])
+@pytest.mark.parametrize("n", [1, 10, 11, 27, 40])
+def test_projection_in_one_loop(lib, oracle, W, H, n):
+    """fs_k_project_n == divergence + clear + n pressureSolve sweeps + subtractGradient (Solver:522-547), bit for bit
+    in div, p, u and v: divergence from the first launch's tile, gradient from the last launch's registers."""
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    vel = rnd((2, H, W), 52, -2, 2)
+    og = full_grid(W, H)
+    div = np.zeros((H, W), F)
+    oracle.divergence(og, vel[0], vel[1], div)
+    a, b = np.zeros((H, W), F), np.zeros((H, W), F)
+    for _ in range(n):
+        oracle.pressureSolve(og, div, a, b)
+        a, b = b, a
+    e = vel.copy()
+    oracle.subtractGradient(og, a, e[0], e[1])
+    g = grid(W, H)
+    dv, dd = dev_planes(vel), dev_planes(rnd((H, W), 53))                   # div holds garbage beforehand
+    pa, pb = dev_planes(rnd((H, W), 54)), dev_planes(rnd((H, W), 55))       # and so do both pressure planes
+    in_b = C.c_int(-1)
+    ok(lib.fs_k_project_n(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(dd), ptr(pa), ptr(pb), n, C.byref(in_b), stream()))
+    sync()
+    assert np.array_equal(host_planes(dd, W)[0], div)
+    assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
+    assert np.array_equal(host_planes(dv, W), e)
