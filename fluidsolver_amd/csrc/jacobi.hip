@@ -98,8 +98,12 @@ __device__ __forceinline__ Row sweep_row(const Row &c, const Row &up, const Row 
         n.a = ((sa + up.a) + dn.a) * quarter;
         n.b = ((sb + up.b) + dn.b) * quarter;
     } else {
-        float t0 = lx + c.a.y, t1 = c.a.x + c.b.x, t2 = c.a.y + c.b.y, t3 = c.b.x + rw;
-        FS_SCALAR(t0); FS_SCALAR(t1); FS_SCALAR(t2); FS_SCALAR(t3);
+        // t1, t2 as two scalar adds straight into their halves of the pairs {t0,t1} / {t2,t3}: left to itself the
+        // compiler forms ONE packed add (c.a + c.b) and then needs two moves to split its result over the pairs
+        float t0 = lx + c.a.y, t3 = c.b.x + rw, t1, t2;
+        asm("v_add_f32 %0, %1, %2" : "=v"(t1) : "v"(c.a.x), "v"(c.b.x));
+        asm("v_add_f32 %0, %1, %2" : "=v"(t2) : "v"(c.a.y), "v"(c.b.y));
+        FS_SCALAR(t0); FS_SCALAR(t3);
         const v2f av = {a, a};
         const v2f xa = c.a + av * ((v2f{t0, t1} + up.a) + dn.a);
         const v2f xb = c.b + av * ((v2f{t2, t3} + up.b) + dn.b);
@@ -109,8 +113,39 @@ __device__ __forceinline__ Row sweep_row(const Row &c, const Row &up, const Row 
     return n;
 }
 
-// T sweeps on the register tile.  EDGE = the tile touches a fixed (boundary / outside) row or column;
-// interior tiles (the vast majority) run the lean instantiation with no selects at all.
+// One sweep src -> dst on the register tile (dst and src are different registers: no copies to keep the previous
+// row alive).  EDGE = the tile touches a fixed (boundary / outside) row or column; interior tiles (the vast
+// majority) run the lean instantiation with no selects at all.
+template <int OP, int R, int NW, bool EDGE>
+__device__ __forceinline__ void sweep_once(const Row (&src)[R], Row (&dst)[R], const Row (&d)[R], float4 (*xch)[NW][2][64],
+                                           int buf, int lane, int wave, int wup, int wdn, unsigned rowfixed, bool fx0,
+                                           bool fx1, bool fx2, bool fx3, float a, double rden)
+{
+    xch[buf][wave][0][lane] = f4_of(src[0]);
+    xch[buf][wave][1][lane] = f4_of(src[R - 1]);
+    __syncthreads();
+    const Row above = row_of(xch[buf][wup][1][lane]);    // row above this wave's strip
+    const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const Row &c = src[i];
+        const Row &up = i > 0 ? src[i - 1] : above;
+        const Row &nx = i < R - 1 ? src[i + 1] : below;
+        Row n = sweep_row<OP>(c, up, nx, d[i], a, rden);
+        if (EDGE) {
+            // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
+            const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
+            if (fx0) n.a.x = fixedv.a.x;
+            if (fx1) n.a.y = fixedv.a.y;
+            if (fx2) n.b.x = fixedv.b.x;
+            if (fx3) n.b.y = fixedv.b.y;
+            if ((rowfixed >> i) & 1u) n = fixedv;
+        }
+        dst[i] = n;
+    }
+}
+
+// T sweeps on the register tile.  Diffuse: two per trip, ping-ponging between p and a second register tile q.
 template <int OP, int R, int NW, bool EDGE>
 __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], float4 (*xch)[NW][2][64], int T,
                                                 int lane, int wave, unsigned rowfixed, bool fx0, bool fx1, bool fx2,
@@ -118,30 +153,44 @@ __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
 {
     const int wup = wave > 0 ? wave - 1 : 0;            // tile rim rows have no neighbour: any value, never used
     const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
-    for (int s = 0; s < T; ++s) {
-        const int buf = s & 1;
-        xch[buf][wave][0][lane] = f4_of(p[0]);
-        xch[buf][wave][1][lane] = f4_of(p[R - 1]);
-        __syncthreads();
-        Row prev = row_of(xch[buf][wup][1][lane]);           // row above this wave's strip
-        const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
+    if (OP == OP_PRESSURE) {
+        // p, q and the divergence tile do not fit 64 VGPRs: one tile, rows rotated in place
+        for (int s = 0; s < T; ++s) {
+            const int buf = s & 1;
+            xch[buf][wave][0][lane] = f4_of(p[0]);
+            xch[buf][wave][1][lane] = f4_of(p[R - 1]);
+            __syncthreads();
+            Row prev = row_of(xch[buf][wup][1][lane]);
+            const Row below = row_of(xch[buf][wdn][0][lane]);
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const Row c = p[i];
-            const Row nx = (i < R - 1) ? p[i + 1] : below;
-            Row n = sweep_row<OP>(c, prev, nx, d[i], a, rden);
-            if (EDGE) {
-                // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
-                const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
-                if (fx0) n.a.x = fixedv.a.x;
-                if (fx1) n.a.y = fixedv.a.y;
-                if (fx2) n.b.x = fixedv.b.x;
-                if (fx3) n.b.y = fixedv.b.y;
-                if ((rowfixed >> i) & 1u) n = fixedv;
+            for (int i = 0; i < R; ++i) {
+                const Row c = p[i];
+                const Row nx = (i < R - 1) ? p[i + 1] : below;
+                Row n = sweep_row<OP>(c, prev, nx, d[i], a, rden);
+                if (EDGE) {
+                    const Row fixedv = Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}};   // pressureOut = 0, Shaders:201-204
+                    if (fx0) n.a.x = fixedv.a.x;
+                    if (fx1) n.a.y = fixedv.a.y;
+                    if (fx2) n.b.x = fixedv.b.x;
+                    if (fx3) n.b.y = fixedv.b.y;
+                    if ((rowfixed >> i) & 1u) n = fixedv;
+                }
+                p[i] = n;
+                prev = c;
             }
-            p[i] = n;
-            prev = c;
         }
+        return;
+    }
+    Row q[R];
+    int s = 0;
+    for (; s + 1 < T; s += 2) {
+        sweep_once<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+        sweep_once<OP, R, NW, EDGE>(q, p, d, xch, 1, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+    }
+    if (s < T) {
+        sweep_once<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+#pragma unroll
+        for (int i = 0; i < R; ++i) p[i] = q[i];
     }
 }
 

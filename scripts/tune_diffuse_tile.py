@@ -14,8 +14,8 @@ s.write_field(L.FIELD_VELOCITY, rng.uniform(-1, 1, (2, H, W)).astype(np.float32)
 ms = C.c_float()
 names = {4: "4x16", 7: "5x16", 6: "6x16"}
 for rep in range(3):
-    for var in (4, 7, 6):
-        for depth in (7, 8, 9, 10):
+    for var in (4, 7):
+        for depth in (6, 7, 8, 9, 10, 12):
             L.check(lib.fs_config_set(L.OPT_TILE_VARIANT_DIFFUSE, var)); L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, depth))
             s.stage(L.STAGE_DIFFUSE_VELOCITY, 40); s.sync()
             L.check(lib.fs_timer_begin(s.ctx), s.ctx)
