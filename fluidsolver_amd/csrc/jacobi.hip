@@ -41,6 +41,7 @@ struct JacobiArgs {
     float *gu, *gv;    // gradient epilogue (EPI): velocity planes updated in place from the final iterate
     const float *du, *dv;   // divergence prologue (PRO): velocity planes the divergence is computed from ...
     float *div_out;         // ... and the plane it is stored to (for the later launches of the loop)
+    unsigned *cfl;          // EPI on a slab: max |v| of the updated v plane over the stored rows (atomicMax), or null
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
     int xcd_chunked;   // tile order, see the kernel
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         __syncthreads();
         Row prev = row_of(xch[buf][wup][1][lane]);
         const Row below = row_of(xch[buf][wdn][0][lane]);
+        float vmax = 0.0f;   // slabs: CFL bound of the backtrace, max |v| over the stored in-domain cells
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const Row c = p[i];
@@ -339,18 +341,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
             if (col_out && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) {
                 const size_t o = row_off(g, y) + gx;
                 st4(out + o, f4_of(c));
-                if (!((rowfixed >> i) & 1u)) {         // boundary rows keep their velocity (Shaders:230-233)
+                const bool rf = (rowfixed >> i) & 1u;      // boundary rows keep their velocity (Shaders:230-233)
+                if (!rf || A.cfl) {
                     float4 uu = ld4(A.gu + o), vv = ld4(A.gv + o);
-                    // vel.x -= 0.5 (p_r - p_l); vel.y -= 0.5 (p_b - p_t)                Shaders:240-243
-                    if (!fx0) { uu.x = uu.x - 0.5f * (c.a.y - lx);    vv.x = vv.x - 0.5f * (nx.a.x - prev.a.x); }
-                    if (!fx1) { uu.y = uu.y - 0.5f * (c.b.x - c.a.x); vv.y = vv.y - 0.5f * (nx.a.y - prev.a.y); }
-                    if (!fx2) { uu.z = uu.z - 0.5f * (c.b.y - c.a.y); vv.z = vv.z - 0.5f * (nx.b.x - prev.b.x); }
-                    if (!fx3) { uu.w = uu.w - 0.5f * (rw - c.b.x);    vv.w = vv.w - 0.5f * (nx.b.y - prev.b.y); }
-                    st4(A.gu + o, uu);
-                    st4(A.gv + o, vv);
+                    if (!rf) {
+                        // vel.x -= 0.5 (p_r - p_l); vel.y -= 0.5 (p_b - p_t)            Shaders:240-243
+                        if (!fx0) { uu.x = uu.x - 0.5f * (c.a.y - lx);    vv.x = vv.x - 0.5f * (nx.a.x - prev.a.x); }
+                        if (!fx1) { uu.y = uu.y - 0.5f * (c.b.x - c.a.x); vv.y = vv.y - 0.5f * (nx.a.y - prev.a.y); }
+                        if (!fx2) { uu.z = uu.z - 0.5f * (c.b.y - c.a.y); vv.z = vv.z - 0.5f * (nx.b.x - prev.b.x); }
+                        if (!fx3) { uu.w = uu.w - 0.5f * (rw - c.b.x);    vv.w = vv.w - 0.5f * (nx.b.y - prev.b.y); }
+                        st4(A.gu + o, uu);
+                        st4(A.gv + o, vv);
+                    }
+                    if (A.cfl) {   // padding columns are don't-care
+                        if (gx + 0 < g.W) vmax = fmaxf(vmax, fabsf(vv.x));
+                        if (gx + 1 < g.W) vmax = fmaxf(vmax, fabsf(vv.y));
+                        if (gx + 2 < g.W) vmax = fmaxf(vmax, fabsf(vv.z));
+                        if (gx + 3 < g.W) vmax = fmaxf(vmax, fabsf(vv.w));
+                    }
                 }
             }
             prev = c;
+        }
+        if (A.cfl) {   // one atomicMax per wave (non-negative floats order like their bit patterns)
+            for (int s = 32; s > 0; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s));
+            if (lane == 0 && vmax > 0.0f) atomicMax(A.cfl, __float_as_uint(vmax));
         }
         return;
     }
@@ -395,7 +410,7 @@ static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, h
 template <int OP>
 static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
                         int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream,
-                        const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr)
+                        const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr, float *cfl = nullptr)
 {
     JacobiArgs A;
     A.g = make_gk(g);
@@ -411,6 +426,7 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.du = du;
     A.dv = dv;
     A.div_out = div_out;
+    A.cfl = reinterpret_cast<unsigned *>(cfl);
     A.TE = T + (gu ? 1 : 0);
     A.HX = (A.TE + 3) & ~3;
     A.a = a;
@@ -438,7 +454,8 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
 template <int OP>
 static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
                       size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
-                      float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr)
+                      float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr,
+                      float *cfl = nullptr)
 {
     const int ex = gu ? 1 : 0;   // the gradient epilogue reads one more ring of the final iterate
     const int need_lo = g->yb - n - ex > 0 ? g->yb - n - ex : 0;
@@ -466,7 +483,7 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
         const bool pro = div_prologue && first && !last;
         int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
                                   last ? gu : nullptr, last ? gv : nullptr, stream, pro ? gu : nullptr, pro ? gv : nullptr,
-                                  pro ? div_out : nullptr);
+                                  pro ? div_out : nullptr, last ? cfl : nullptr);
         if (rc) return rc;
         float *t = src; src = dst; dst = t;
         src_zero = false;
@@ -576,21 +593,32 @@ int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa,
     return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v);
 }
 
-int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, int *result_in_b,
-                   void *stream)
+int fs_k_project_n_cfl(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
+                       int *result_in_b, void *stream)
 {
     int rc = check_grid(g);
     if (rc) return rc;
     REQUIRE(u && v && div && pa && pb && pa != pb, "bad pointers");
     REQUIRE(n >= 1, "needs at least one sweep");
-    REQUIRE(g->yb == 0 && g->ye == g->height && g->y0 == 0 && g->rows == g->height, "the whole grid on one GPU only");
     if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb) return FS_OK;
     if (jacobi_launch_count(OP_PRESSURE, n) < 2) {
-        // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads)
-        rc = fs_k_divergence(g, u, v, div, stream);
+        // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads):
+        // the divergence of the rows the sweeps read stays a separate pass
+        fs_grid gd = *g;
+        gd.yb = g->yb - n > g->y0 ? g->yb - n : g->y0;
+        gd.ye = g->ye + n < g->y0 + g->rows ? g->ye + n : g->y0 + g->rows;
+        rc = fs_k_divergence(&gd, u, v, div, stream);
         if (rc) return rc;
     }
-    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div);
+    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div,
+                                   cfl_dev);
+}
+
+int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, int *result_in_b,
+                   void *stream)
+{
+    return fs_k_project_n_cfl(g, u, v, div, pa, pb, n, nullptr, result_in_b, stream);
 }
 
 int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)

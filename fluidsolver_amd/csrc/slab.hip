@@ -268,8 +268,11 @@ struct Planner {
             sweeps(false, F_VEL, N, need_v2);
         }
         need(F_VEL, need_v2);
-        const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
-        const bool project_fused = !multi && (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0;
+        // The projection in one loop (fs_k_project_n): while the loop's planes sit in the Infinity Cache.  A slab needs
+        // N + 1 ghost rows of velocity for it (it has them whenever the capacity allows: need_v2 = N + 1).
+        const double loop_rows = multi ? (double)(c->H / c->world + 2 * (N + 1)) : (double)c->H;   // the same on every rank
+        const bool cache_resident = 3.0 * (double)c->pitch * loop_rows * sizeof(float) < 192.0 * 1024 * 1024;
+        const bool project_fused = (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0 && (!multi || G >= N + 1);
         const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
         if (!project_fused) {
             const fs_grid g = grid_of(c, dd);
@@ -284,7 +287,21 @@ struct Planner {
         // 16384^2 the loop streams from HBM, the extra 16 B/cell no longer ride for free and it costs 0.3 %
         // (profiles/r01_h_ab_fuse*.log), so the separate pass is kept there.
         const bool grad_fused = project_fused;
-        if (N > 0) {
+        if (project_fused && multi) {
+            const fs_grid g = grid_of(c, 0);
+            Field &P = c->f[F_P];
+            float *u = V.p(), *v = u + plane, *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = c->cfl_dev;
+            compute("project_n_cfl", g, N, [=]() {                                    // :522-547 + the CFL bound
+                hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
+                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
+                int ib = 0;
+                return fs_k_project_n_cfl(&g, u, v, dw, src, dst, N, cfl, &ib, st);
+            });
+            if (jacobi_launch_count(0, N) & 1) P.cur ^= 1;
+            P.valid = 0;
+            c->f[F_DIV].valid = 0;
+            c->p_zero = false;
+        } else if (N > 0) {
             sweeps(true, F_P, N, need_p, grad_fused);                                 // :533-541 (+ :544-547)
         } else {
             const fs_grid g = grid_of(c, G);
@@ -292,7 +309,7 @@ struct Planner {
             compute("clear", g, 0, [=]() { return fs_k_clear(&g, pp, 1, 0, st); });
             c->p_zero = false;
         }
-        need(F_P, 1);
+        if (!grad_fused) need(F_P, 1);
         {
             const fs_grid g = grid_of(c, 0);
             float *u = V.p(), *v = u + plane, *pp = c->f[F_P].p();

@@ -69,6 +69,7 @@ SIGNATURES = {
     "fs_k_pressureSolve_n": (_i, [_G, _p, _p, _p, _i, _i, C.POINTER(_i), _p]),
     "fs_k_subtractGradient": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_project_n": (_i, [_G, _p, _p, _p, _p, _p, _i, C.POINTER(_i), _p]),
+    "fs_k_project_n_cfl": (_i, [_G, _p, _p, _p, _p, _p, _i, _p, C.POINTER(_i), _p]),
     "fs_k_pressureSolve_n_gradient": (_i, [_G, _p, _p, _p, _i, _i, _p, _p, C.POINTER(_i), _p]),
     "fs_k_calculateVorticity": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_applyVorticity": (_i, [_G, _p, _p, _p, _f, _f, _p]),

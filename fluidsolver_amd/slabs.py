@@ -95,6 +95,13 @@ class HipBackend:
                                         self._p(pb), n, C.byref(in_b), self._s()))
         return bool(in_b.value)
 
+    def project_n_cfl(self, g, vel, div, pa, pb, n, out):
+        out.zero_()
+        in_b = C.c_int(0)
+        L.check(self.lib.fs_k_project_n_cfl(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(div), self._p(pa),
+                                            self._p(pb), n, C.c_void_p(out.data_ptr()), C.byref(in_b), self._s()))
+        return bool(in_b.value)
+
     def clear(self, g, t):
         L.check(self.lib.fs_k_clear(C.byref(g), self._p(t), t.shape[0], t.stride(0), self._s()))
 
@@ -362,10 +369,13 @@ class SlabSolver:
             self._need("vel", need_v1)
             self._sweeps("diffuse", "vel", N, need_v2)
         self._need("vel", need_v2)
-        # one GPU: the divergence is computed by the first pressure launch and the gradient subtracted by the last,
-        # from registers (while the loop's planes sit in the Infinity Cache; beyond that separate passes are faster)
-        cache_resident = 3.0 * self.pitch * self.H * 4 < 192.0 * 1024 * 1024
-        grad_fused = not multi and N > 0 and cache_resident and hasattr(self.be, "project_n")
+        # The projection in one loop (fs_k_project_n): the divergence is computed by the first pressure launch and the
+        # gradient subtracted by the last, from registers -- while the loop's planes sit in the Infinity Cache (beyond
+        # that separate passes are faster).  A slab needs N + 1 ghost rows of velocity for it.
+        loop_rows = (self.H // self.world + 2 * (N + 1)) if multi else self.H      # the same on every rank
+        cache_resident = 3.0 * self.pitch * loop_rows * 4 < 192.0 * 1024 * 1024
+        grad_fused = (N > 0 and cache_resident and hasattr(self.be, "project_n")
+                      and (not multi or (self.G >= N + 1 and hasattr(self.be, "project_n_cfl"))))
         dd = min(need_div, eff("vel") - 1) if multi else 0
         if not grad_fused:
             self.be.divergence(self.grid(dd), self.f["vel"], self.f["div"])    # :522-525
@@ -373,20 +383,29 @@ class SlabSolver:
             V["div"] = dd
         self._p_zero = True                                                    # clear folded in, :528-530
         V["p"] = INF
-        if N > 0:
+        if grad_fused and multi:
+            in_b = self.be.project_n_cfl(self.grid(0), self.f["vel"], self.f["div"], self.f["p"], self.f["p_t"], N,
+                                         self.cfl)                             # :522-547 + the CFL bound
+            if in_b:
+                self.f["p"], self.f["p_t"] = self.f["p_t"], self.f["p"]
+            V["p"], V["div"] = 0, 0
+            self._p_zero = False
+        elif N > 0:
             self._sweeps("pressure", "p", N, need_p, grad_fused)               # :533-541 (+ :544-547)
         else:
             self.be.clear(self.grid(self.G), self.f["p"])
-        self._need("p", 1)
+        if not grad_fused:
+            self._need("p", 1)
         # ---- advection: halo from the CFL bound of the backtrace ----
         h = 0
-        if grad_fused:
+        if grad_fused and not multi:
             pass
         elif not multi:
             self.be.subtractGradient(self.grid(0), self.f["p"], self.f["vel"])     # :544-547
         else:
             # ... with max |v_y| of the owned rows in the same pass, then max over ranks
-            self.be.subtractGradient_cfl(self.grid(0), self.f["p"], self.f["vel"], self.cfl)
+            if not grad_fused:
+                self.be.subtractGradient_cfl(self.grid(0), self.f["p"], self.f["vel"], self.cfl)
             V["vel"] = 0
             self.comm.allreduce_max(self.cfl)
             # bilinear taps lie within ceil(|v_y| dt) + 1 rows; +1 more because the dye is traced through

@@ -129,12 +129,17 @@ int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *p
 int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa, float *pb, int n,
                                   int p_is_zero, float *u, float *v, int *result_in_b, void *stream);
 
-/* The whole projection of update(), Solver:522-547, on one GPU's whole grid: divergence + clearTexture + n
- * pressureSolve sweeps + subtractGradient, with the divergence computed by the FIRST launch of the loop (and stored
- * to div for the others) and the gradient subtracted by the LAST one.  Same bits in div, p, u, v as the four
- * calls.  n >= 1; with a single launch (n <= block depth) the divergence stays a separate pass. */
+/* The whole projection of update(), Solver:522-547: divergence + clearTexture + n pressureSolve sweeps +
+ * subtractGradient on rows [yb,ye), with the divergence computed by the FIRST launch of the loop (and stored to div
+ * for the others) and the gradient subtracted by the LAST one.  Same bits in p, u, v on [yb,ye) as the four calls
+ * (div is stored on the rows the later launches read).  n >= 1; with a single launch (n <= block depth) the
+ * divergence stays a separate pass.  On a row range (slab) the buffer must hold n + 1 rows with valid velocity
+ * beyond [yb,ye) (clipped to the domain).  _cfl: also fs_k_max_abs of the new v plane over [yb,ye) into *cfl_dev
+ * (device float holding a lower bound, normally 0) -- the slab runtime's CFL bound, no counterpart in the reference. */
 int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n,
                    int *result_in_b, void *stream);
+int fs_k_project_n_cfl(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n,
+                       float *cfl_dev, int *result_in_b, void *stream);
 
 /* replaces kernel subtractGradient, Shaders:225-245 (velocity in place) */
 int fs_k_subtractGradient(const fs_grid *g, const float *p, float *u, float *v, void *stream);

@@ -85,6 +85,17 @@ class OracleBackend:
         self.subtractGradient(g, pb if in_b else pa, vel)
         return in_b
 
+    def project_n_cfl(self, g, vel, div, pa, pb, n, out):
+        from fluidsolver_amd import lib as L
+        gd = L.Grid(g.width, g.height, g.pitch, g.y0, g.rows, max(g.y0, g.yb - n), min(g.y0 + g.rows, g.ye + n))
+        self.divergence(gd, vel, div)
+        # the gradient reads one row of the final iterate beyond [yb, ye): sweep on that range
+        g1 = L.Grid(g.width, g.height, g.pitch, g.y0, g.rows, max(g.y0, g.yb - 1), min(g.y0 + g.rows, g.ye + 1))
+        in_b = self.pressure_n(g1, div, pa, pb, n, True)
+        self.subtractGradient(g, pb if in_b else pa, vel)
+        self.max_abs(g, vel[1], out)
+        return in_b
+
     def divergence(self, g, vel, div):
         W = g.width
         v, o = self._dense(vel, W), self._dense(div, W)

@@ -567,3 +567,38 @@ def test_projection_in_one_loop(lib, oracle, W, H, n):
     assert np.array_equal(host_planes(dd, W)[0], div)
     assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
     assert np.array_equal(host_planes(dv, W), e)
+
+
+@pytest.mark.parametrize("n", [3, 12, 25])
+def test_projection_with_cfl_on_a_row_range(lib, oracle, n):
+    """fs_k_project_n_cfl as a slab calls it: rows [60, 180) of a 260-row domain from a buffer holding rows
+    [30, 215) -- p, u, v of those rows equal the unsplit oracle's, no other velocity row is touched, and the CFL
+    value is max |v| of exactly those rows after the update."""
+    import torch
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    W, H = 333, 260
+    vel = rnd((2, H, W), 62, -2, 2)
+    og = full_grid(W, H)
+    div = np.zeros((H, W), F)
+    oracle.divergence(og, vel[0], vel[1], div)
+    a, b = np.zeros((H, W), F), np.zeros((H, W), F)
+    for _ in range(n):
+        oracle.pressureSolve(og, div, a, b)
+        a, b = b, a
+    e = vel.copy()
+    oracle.subtractGradient(og, a, e[0], e[1])
+    y0, rows, yb, ye = 30, 185, 60, 180
+    g = grid(W, H, y0=y0, rows=rows, yb=yb, ye=ye)
+    dv, dd = dev_planes(vel[:, y0:y0 + rows]), dev_planes(rnd((rows, W), 63))
+    pa, pb = dev_planes(rnd((rows, W), 64)), dev_planes(rnd((rows, W), 65))
+    cfl = torch.zeros(1, dtype=torch.float32, device="cuda")
+    in_b = C.c_int(-1)
+    ok(lib.fs_k_project_n_cfl(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(dd), ptr(pa), ptr(pb), n, C.c_void_p(cfl.data_ptr()),
+                              C.byref(in_b), stream()))
+    sync()
+    got = host_planes(dv, W)
+    assert np.array_equal(got[:, yb - y0:ye - y0], e[:, yb:ye])
+    assert np.array_equal(got[:, :yb - y0], vel[:, y0:yb]) and np.array_equal(got[:, ye - y0:], vel[:, ye:y0 + rows])
+    assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0][yb - y0:ye - y0], a[yb:ye])
+    assert float(cfl.item()) == float(np.abs(e[1][yb:ye]).max())

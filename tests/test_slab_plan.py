@@ -52,6 +52,11 @@ class _Recorder:
         self._rec("project_n", g, n)
         return bool(self._launches(0, n) & 1)
 
+    def project_n_cfl(self, g, vel, div, pa, pb, n, out):
+        self._rec("project_n_cfl", g, n)
+        out.fill_(self.next_cfl)
+        return bool(self._launches(0, n) & 1)
+
     @staticmethod
     def _launches(op, n):
         from fluidsolver_amd import lib as L
