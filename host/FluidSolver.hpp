@@ -198,6 +198,17 @@ class ParticleSystem {
         if (rc) throw Error(rc, fs_last_error(s_.ctx()));
     }
     long particleCount() { return fs_particles_count(s_.ctx()); }
+    float particleSize = 1.0f;  // Part:111
+    // What render(in:viewportSize:) draws (Part:341-363 -> particleVertex, Shaders:446-476): per tracer the line
+    // (pos - vel * particleSize, pos) in NDC as (x0, y0, x1, y1), and alpha = life.
+    void lineVertices(float2 viewportSize, std::vector<float> &xy4, std::vector<float> &alpha)
+    {
+        const size_t n = (size_t)particleCount();
+        xy4.resize(4 * n);
+        alpha.resize(n);
+        int rc = fs_particle_lines(s_.ctx(), viewportSize.x, viewportSize.y, particleSize, xy4.data(), alpha.data());
+        if (rc) throw Error(rc, fs_last_error(s_.ctx()));
+    }
 
   private:
     FluidSolver &s_;

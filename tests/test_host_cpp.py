@@ -17,7 +17,7 @@ def test_cpp_host_builds():
     assert os.path.exists(os.path.join(ROOT, "host", "demo"))
     src = open(os.path.join(ROOT, "host", "FluidSolver.hpp")).read()
     for name in ("setResolution", "reset", "applyPreset", "addForce", "endInteraction", "update", "texture",
-                 "getVelocityAt", "class ParticleSystem"):
+                 "getVelocityAt", "class ParticleSystem", "lineVertices"):
         assert name in src
 
 
