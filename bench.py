@@ -97,13 +97,14 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=25):
     return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
 
 
-def cpu_baseline(W, H, params, budget_s=20.0):
-    """The scalar oracle ("port", 1 thread) on a bounded sample of the same workload: whole frames of
-    the same scripted input, as many as fit the budget (at least 1)."""
+def cpu_baseline(W, H, params, budget_s=20.0, omp=False):
+    """The scalar oracle ("port", 1 thread; omp=True: the same code with OpenMP over rows on the box's CPU share,
+    bit-identical) on a bounded sample of the same workload: whole frames of the same scripted input, as many as
+    fit the budget (at least 1)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle, Params
     from fluidsolver_amd.script import splat
-    o = Oracle(omp=False)
+    o = Oracle(omp=omp)
     s = o.solver(W, H)
     p = Params(*params)
     frames, t0 = 0, time.perf_counter()
@@ -116,9 +117,10 @@ def cpu_baseline(W, H, params, budget_s=20.0):
         if el > budget_s or el * (frames + 1) / frames > budget_s * 1.5:
             break
     fps = frames / el
-    return dict(value=W * H * fps / 1e9, unit="Gcell-updates/s", cores=1, kind="port",
+    threads = o.threads() if omp else 1
+    return dict(value=W * H * fps / 1e9, unit="Gcell-updates/s", cores=threads, kind="port",
                 sample="%d whole frame(s) of the same %dx%d scripted workload, scalar C oracle (gcc -O2 "
-                       "-ffp-contract=off), %.1f s" % (frames, W, H, el),
+                       "-ffp-contract=off%s), %.1f s" % (frames, W, H, ", OpenMP over rows" if omp else "", el),
                 frames_per_s=fps, host_cpus=os.cpu_count())
 
 
@@ -353,6 +355,7 @@ def main():
                                    "effective figure may exceed the HBM peak"}
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
+            out["cpu_baseline_all_cores"] = cpu_baseline(W, H, params, budget_s=8.0, omp=True)
     if slabs:
         st = s.stats
         out["slab"] = {"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
