@@ -266,7 +266,15 @@ def main():
         from fluidsolver_amd.native_slabs import RcclSlab
         # Control plane (RCCL unique id, barriers, max of the timings): torch.distributed over gloo.
         # Data plane (halo rows, CFL all-reduce): ncclSend/ncclRecv/ncclAllReduce inside the library.
-        dist.init_process_group("gloo")
+        # (gloo announces its connections on fd 1; stdout is reserved for the one JSON line, so it goes to stderr)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         H = Hg * world if wl["scaling"] == "weak" else Hg
         s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
         L.check(lib.fs_comm_selftest(s.comm, 1 << 16))
@@ -357,8 +365,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(W, H, params)
             out["cpu_baseline_all_cores"] = cpu_baseline(W, H, params, budget_s=8.0, omp=True)
     if slabs:
+        # untimed: a few more frames with every wait for halo rows timed on the GPU (what was NOT hidden)
+        s.set_profile(True)
+        s.waits()
+        pf = 10
+        for f in range(f0 + args.warmup + args.steps, f0 + args.warmup + args.steps + pf):
+            step(f)
+        w = s.waits()
+        s.set_profile(False)
+        wt = torch.tensor([w["vel_ms"], w["dye_ms"], w["blocking_ms"]], dtype=torch.float64)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
         st = s.stats
-        out["slab"] = {"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+        exposed = {"velocity_halo": float(wt[0]) * 1e3 / pf, "dye_halo": float(wt[1]) * 1e3 / pf,
+                   "blocking_exchanges": float(wt[2]) * 1e3 / pf,
+                   "note": "us per frame the kernels waited at joins (max over ranks, HIP events, 10 extra frames)"}
+        out["slab"] = {"exposed_wait_us_per_frame": exposed,"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
                        "overlap": bool(overlap), "advection_replans": st["redo"],

@@ -289,6 +289,8 @@ int fs_destroy(fs_ctx *c)
     if (c->tr_matrix_host) (void)hipHostFree(c->tr_matrix_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto *list : {&c->probes_live, &c->probes_free})
+        for (const fs_ctx::WaitProbe &pr : *list) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->ev_cfl) (void)hipEventDestroy(c->ev_cfl);
     for (int i = 0; i < SLOT_COUNT; ++i) {
@@ -352,6 +354,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
     case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 3) ? value : 1; break;
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
+    case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:
         if (fs::config_set_tile_variant(-1, value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;

@@ -92,6 +92,13 @@ struct fs_ctx {
     bool pending[fs::SLOT_COUNT] = {false, false, false};
     hipEvent_t ev_cfl = nullptr;        // CFL value has landed in cfl_host
     int overlap = 1;                    // FS_OPT_SLAB_OVERLAP: speculative halo + split advection
+    // FS_OPT_SLAB_PROFILE: timed event pairs around every join, so a run can report how long the kernels really
+    // waited for halo rows (the part of the traffic that was NOT hidden)
+    int profile = 0;
+    struct WaitProbe { hipEvent_t a, b; int slot; };
+    std::vector<WaitProbe> probes_live, probes_free;
+    double wait_ms[fs::SLOT_COUNT] = {0.0, 0.0, 0.0};
+    long wait_count[fs::SLOT_COUNT] = {0, 0, 0};
     int halo_hist[4] = {-1, -1, -1, -1};   // advection halos the last frames really needed (-1: unknown), newest first
     fs_params params{};
     int use_graph = 1;

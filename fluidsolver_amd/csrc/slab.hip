@@ -546,7 +546,18 @@ namespace {
 int join_slot(fs_ctx *c, int slot)
 {
     if (!c->pending[slot]) return FS_OK;
+    fs_ctx::WaitProbe pr{nullptr, nullptr, slot};
+    const bool probe = c->profile && c->probes_live.size() < 8192;
+    if (probe) {
+        if (!c->probes_free.empty()) { pr = c->probes_free.back(); c->probes_free.pop_back(); pr.slot = slot; }
+        else { FS_HIP(hipEventCreate(&pr.a)); FS_HIP(hipEventCreate(&pr.b)); }
+        FS_HIP(hipEventRecord(pr.a, c->stream));
+    }
     FS_HIP(hipStreamWaitEvent(c->stream, c->ev_slot[slot], 0));
+    if (probe) {
+        FS_HIP(hipEventRecord(pr.b, c->stream));
+        c->probes_live.push_back(pr);
+    }
     c->pending[slot] = false;
     return FS_OK;
 }
@@ -1036,6 +1047,27 @@ int fs_slab_info(fs_ctx *c, int info[6])
 {
     if (!c || !info) return FS_ERR_INVALID;
     info[0] = c->r0; info[1] = c->r1; info[2] = c->b0; info[3] = c->b1; info[4] = c->G; info[5] = c->last_halo;
+    return FS_OK;
+}
+
+// Milliseconds the kernels of this slab waited at joins since the last call, per slot (velocity halo, dye halo,
+// blocking exchanges), and the number of joins measured; needs FS_OPT_SLAB_PROFILE = 1.  Blocks like fs_sync.
+int fs_slab_waits(fs_ctx *c, double wait_ms[3], long joins[3])
+{
+    CTX(c);
+    if (!wait_ms || !joins) { set_error("fs_slab_waits: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
+    if (c->xstream) TRYHIP(c, hipStreamSynchronize(c->xstream));
+    TRYHIP(c, hipStreamSynchronize(c->stream));
+    for (const fs_ctx::WaitProbe &pr : c->probes_live) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) { c->wait_ms[pr.slot] += ms; c->wait_count[pr.slot] += 1; }
+        c->probes_free.push_back(pr);
+    }
+    c->probes_live.clear();
+    for (int i = 0; i < SLOT_COUNT; ++i) {
+        wait_ms[i] = c->wait_ms[i]; joins[i] = c->wait_count[i];
+        c->wait_ms[i] = 0.0; c->wait_count[i] = 0;
+    }
     return FS_OK;
 }
 

@@ -101,6 +101,17 @@ class _Slab:
         L.check(self.lib.fs_slab_stats(self.ctx, st))
         return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2], "redo": st[3], "tracers_received": st[4]}
 
+    def set_profile(self, on):
+        """FS_OPT_SLAB_PROFILE: time every wait of the kernels for halo rows (read with waits())."""
+        L.check(self.lib.fs_set_option(self.ctx, L.OPT_SLAB_PROFILE, 1 if on else 0), self.ctx)
+
+    def waits(self):
+        """Since the last call: ms the kernels waited for the velocity halo, the dye halo and blocking exchanges,
+        and the number of waits timed.  Blocks."""
+        ms, n = (C.c_double * 3)(), (C.c_long * 3)()
+        L.check(self.lib.fs_slab_waits(self.ctx, ms, n), self.ctx)
+        return {"vel_ms": ms[0], "dye_ms": ms[1], "blocking_ms": ms[2], "joins": [n[0], n[1], n[2]]}
+
     # ---- tracers (SURVEY 8(f) rank 4): each lives on the rank that owns the row its lookup reads ----
     def particles_reserve(self, capacity, window=None, **params):
         """Room for `capacity` tracers on THIS rank; turns the tracer step of update() on.  params: fields of

@@ -255,6 +255,7 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */
+       FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
        FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* fs_config_set/get only: tile shape of the diffuse loops alone */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
@@ -361,6 +362,9 @@ int fs_comm_selftest(fs_comm *comm, int count);
 int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out);
 int fs_slab_info(fs_ctx *ctx, int info[6]);   /* r0, r1 (owned rows), b0, b1 (buffered rows), ghost capacity, last advection halo */
 int fs_slab_stats(fs_ctx *ctx, long stats[5]); /* exchange rounds, halo rows sent, frames, advection re-plans (halo guessed too small), tracers received */
+/* With FS_OPT_SLAB_PROFILE = 1: milliseconds this slab's kernels spent waiting for halo rows since the last call
+ * -- [0] velocity halo, [1] dye halo, [2] blocking exchanges -- and how many waits were timed.  Blocks like fs_sync. */
+int fs_slab_waits(fs_ctx *ctx, double wait_ms[3], long joins[3]);
 int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
 /* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
  * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f;

@@ -294,3 +294,32 @@ def test_tracer_capacity_is_checked():
         assert e.value.code == -3 and "capacity" in str(e.value)
     finally:
         g.close()
+
+
+def test_join_waits_are_measured():
+    """FS_OPT_SLAB_PROFILE: every wait of a slab's kernels for halo rows is timed on the GPU (bench.py reports the
+    sums at N > 1, so the next look at the links has data); results are unchanged by it."""
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params = 512, 768, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 10)
+    runs = []
+    for profile in (False, True):
+        g = LocalGroup(W, H, params, 3, device=0, asynchronous=True, overlap=True)
+        try:
+            for sl in g.slabs:
+                sl.set_profile(profile)
+            for f in range(5):
+                pos, force, col = splat(W, H, 4 * f + 1)
+                g.add_force(pos, force, col)
+                g.update()
+            g.sync()
+            w = [sl.waits() for sl in g.slabs]
+            runs.append((g.field("vel"), g.field("dye"), w))
+        finally:
+            g.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert all(sum(x["joins"]) == 0 for x in runs[0][2])
+    mid = runs[1][2][1]                      # the middle slab has two neighbours
+    assert mid["joins"][0] >= 4 and mid["joins"][1] >= 3, mid
+    assert all(v >= 0.0 for v in (mid["vel_ms"], mid["dye_ms"], mid["blocking_ms"]))
+    assert sum(runs[1][2][1]["joins"]) > 0 and sum(sl["joins"][0] for sl in runs[1][2]) > 0
