@@ -337,6 +337,105 @@ __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const floa
 }
 
 // ---------------------------------------------------------------------------
+// Both advections of update() in one pass (Solver:550-558 velocity by itself, :577-591 dye by the NEW velocity,
+// then fade): the dye is traced through the velocity this very thread has just produced for the same cell, so
+// the advected velocity is not read back (8 B/cell less) and one launch disappears.  Same operations per cell,
+// in the same order, as k_advect<2,false> followed by k_advect<3,true>.
+// ---------------------------------------------------------------------------
+struct Trace {
+    size_t o0[4], o1[4];
+    float sx[4], sy[4];
+};
+__device__ __forceinline__ bool backtrace4(const GK &g, const Quad &q, const float (&ux)[4], const float (&vy)[4], float dt,
+                                           const bool (&bnd)[4], Trace &t)
+{
+    bool short_halo = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = q.x + j;
+        float posx = (float)x - ux[j] * dt;                       // :132-133
+        float posy = (float)q.y - vy[j] * dt;
+        posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
+        posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
+        const int i0x = (int)floorf(posx);                        // :140
+        int i0y = (int)floorf(posy);
+        t.sx[j] = posx - (float)i0x;                              // :142
+        t.sy[j] = posy - (float)i0y;
+        int i1y = i0y + 1;
+        if (i0y < g.y0 || i1y >= g.y0 + g.rows) {                 // slab halo too small: flag, stay in bounds
+            short_halo |= !bnd[j];
+            i0y = clamp_row(g, i0y);
+            i1y = clamp_row(g, i1y);
+        }
+        t.o0[j] = row_off(g, i0y) + i0x;
+        t.o1[j] = row_off(g, i1y) + i0x;
+    }
+    return short_halo;
+}
+__device__ __forceinline__ void gather4(const float *p, const Trace &t, float (&r)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const TapPair r0 = ld_pair(p + t.o0[j]), r1 = ld_pair(p + t.o1[j]);   // :144-147
+        const float m0 = r0.a + (r0.b - r0.a) * t.sx[j];          // :149 mix(mix(),mix(),s.y)
+        const float m1 = r1.a + (r1.b - r1.a) * t.sx[j];
+        r[j] = m0 + (m1 - m0) * t.sy[j];
+    }
+}
+template <bool FADE>
+__global__ __launch_bounds__(256, 8) void k_advect_both(GK g, int yb, int ye, const float *__restrict__ u,
+                                                     const float *__restrict__ v, float *__restrict__ uo,
+                                                     float *__restrict__ vo, const float *__restrict__ dye,
+                                                     float *__restrict__ dye_out, size_t stride, float dt, int *err,
+                                                     float fade_k)
+{
+    const Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    const size_t o = row_off(g, q.y) + q.x;
+    const float4 uu = ld4(u + o), vv = ld4(v + o);
+    const float ux[4] = {uu.x, uu.y, uu.z, uu.w}, vy[4] = {vv.x, vv.y, vv.z, vv.w};
+    const bool rowb = q.y == 0 || q.y >= g.H - 1;
+    bool bnd[4], any_bnd = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = q.x + j;
+        bnd[j] = rowb || x == 0 || x >= g.W - 1;                  // :127-130 (padding columns count as boundary)
+        any_bnd |= bnd[j];
+    }
+    Trace t;
+    bool short_halo = backtrace4(g, q, ux, vy, dt, bnd, t);
+    float nu[4], nv[4];
+    gather4(u, t, nu);
+    gather4(v, t, nv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (bnd[j]) { nu[j] = ux[j]; nv[j] = vy[j]; }             // boundary cells copy the input, :127-130
+    st4(uo + o, make_float4(nu[0], nu[1], nu[2], nu[3]));
+    st4(vo + o, make_float4(nv[0], nv[1], nv[2], nv[3]));
+    // the dye, through the velocity just computed (Solver:577-582 binds the swapped velocity texture)
+    short_halo |= backtrace4(g, q, nu, nv, dt, bnd, t);
+    if (short_halo && err) atomicOr(err, 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *p = dye + c * stride;
+        float r[4];
+        gather4(p, t, r);
+        if (any_bnd) {
+            const float4 cen = ld4(p + o);
+            if (bnd[0]) r[0] = cen.x;
+            if (bnd[1]) r[1] = cen.y;
+            if (bnd[2]) r[2] = cen.z;
+            if (bnd[3]) r[3] = cen.w;
+        }
+        if (FADE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j] * fade_k, 0.0f);
+        }
+        st4(dye_out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // addForces, Shaders:43-69, on the splat's bounding box only (the reference launches
 // the full grid for <= ~7.9k touched cells).  exp is evaluated in fp64 and rounded
 // once, i.e. a correctly rounded fp32 exp.
@@ -671,6 +770,27 @@ int fs_k_advect_fade(const fs_grid *g, const float *u, const float *v, const flo
                      size_t plane_stride, float deltaTime, float fadeRate, int *err_flag, void *stream)
 {
     return launch_advect(g, u, v, in, out, nplanes, plane_stride, deltaTime, err_flag, true, fadeRate, stream);
+}
+
+int fs_k_advect_both(const fs_grid *g, const float *u, const float *v, float *u_out, float *v_out, const float *dye,
+                     float *dye_out, size_t dye_stride, float deltaTime, int fade, float fadeRate, int *err_flag,
+                     void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && u_out && v_out && dye && dye_out, "null pointer");
+    REQUIRE(u != u_out && v != v_out && dye != dye_out, "advect cannot run in place");
+    EMPTY_OK(g);
+    const dim3 grid = quad_grid(g, 1);
+    const GK gk = make_gk(g);
+    const float k = 1.0f - fadeRate;  // Shaders:331
+    if (fade)
+        hipLaunchKernelGGL(k_advect_both<true>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, u_out, v_out, dye, dye_out,
+                           dye_stride, deltaTime, err_flag, k);
+    else
+        hipLaunchKernelGGL(k_advect_both<false>, grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, u_out, v_out, dye, dye_out,
+                           dye_stride, deltaTime, err_flag, k);
+    FS_LAUNCH_CHECK("k_advect_both");
+    return FS_OK;
 }
 
 int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, float pos_x, float pos_y,

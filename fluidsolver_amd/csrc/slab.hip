@@ -224,6 +224,19 @@ struct Planner {
         else
             compute("advect", g, np, [=]() { return fs_k_advect(&g, u, v, src, dst, np, plane, dt, err, st); });
     }
+    // both advections on rows [yb, ye) in one pass (FS_OPT_FUSE 1); no role swaps
+    void advect_both_rows(int yb, int ye)
+    {
+        Field &V = c->f[F_VEL], &D = c->f[F_DYE];
+        const fs_grid g = grid_rows(yb, ye);
+        const float *u = V.p(), *v = u + c->plane, *dye = D.p();
+        float *uo = V.t(), *vo = uo + c->plane, *dyo = D.t();
+        const size_t plane = c->plane;
+        const float dt = c->params.deltaTime, fr = c->params.fadeSpeed;
+        int *err = c->err_flag;
+        hipStream_t st = c->stream;
+        compute("advect_both", g, 5, [=]() { return fs_k_advect_both(&g, u, v, uo, vo, dye, dyo, plane, dt, 1, fr, err, st); });
+    }
     void advect(int fi, bool fade, int depth = 0)
     {
         advect_rows(fi, fade, c->r0 - depth, c->r1 + depth);
@@ -345,6 +358,10 @@ struct Planner {
         hipStream_t st = c->stream;
         const size_t plane = c->plane;
         const bool fade_fused = c->fuse == 1 || c->fuse == 2;
+        // both advections in one pass: no gain while a plane fits the Infinity Cache (572 vs 570 us per frame at
+        // 3072^2: the advected velocity is read back from the cache anyway), -0.5 % at 16384^2
+        // (profiles/r01_q_ab_fuse_*.log); so only when a plane of the slab is at least as big as the cache
+        const bool both_fused = c->fuse == 1 && (double)c->pitch * (double)(c->H / c->world) * sizeof(float) >= 256.0 * 1024 * 1024;
         // overlap: the advected velocity is also computed on the ghost rows the next frame's stencil
         // chain consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
         const int adv = (multi && c->overlap) ? std::max(0, std::min(chain_needs().v0, G - h)) : 0;
@@ -353,10 +370,14 @@ struct Planner {
             ensure({{F_VEL, h + adv}, {F_DYE, h}}, SLOT_VEL, true);                   // dye: normally prefetched by plan_a
             const int i0 = c->r0 + (c->r0 > 0 ? h : 0), i1 = c->r1 - (c->r1 < c->H ? h : 0);
             // interior rows: no tap of their backtrace leaves the owned rows            :550-558, :577-591
-            advect_rows(F_VEL, false, i0, i1);
-            c->f[F_VEL].cur ^= 1;
-            advect_rows(F_DYE, fade_fused, i0, i1);
-            c->f[F_VEL].cur ^= 1;
+            if (both_fused) {
+                advect_both_rows(i0, i1);
+            } else {
+                advect_rows(F_VEL, false, i0, i1);
+                c->f[F_VEL].cur ^= 1;
+                advect_rows(F_DYE, fade_fused, i0, i1);
+                c->f[F_VEL].cur ^= 1;
+            }
             join(SLOT_VEL);
             advect_rows(F_VEL, false, c->r0 - adv, i0);
             advect_rows(F_VEL, false, i1, c->r1 + adv);
@@ -371,12 +392,18 @@ struct Planner {
                 ensure({{F_VEL, h + adv}, {F_DYE, h + ddn}});                         // one batched round
                 join(SLOT_DYE);                                                       // a prefetch of plan_a, if any
             }
-            advect(F_VEL, false, adv);                                                // :550-558
-            if (ddn) {                                                                // :562-574
-                sweeps(false, F_DYE, N, h);
-                need(F_DYE, h);
+            if (!multi && !ddn && both_fused) {
+                advect_both_rows(c->r0, c->r1);                                       // :550-558 + :577-591 in one pass
+                c->f[F_VEL].cur ^= 1;
+                c->f[F_DYE].cur ^= 1;
+            } else {
+                advect(F_VEL, false, adv);                                            // :550-558
+                if (ddn) {                                                            // :562-574
+                    sweeps(false, F_DYE, N, h);
+                    need(F_DYE, h);
+                }
+                advect(F_DYE, fade_fused);                                            // :577-584 (+ :587-591 when fused)
             }
-            advect(F_DYE, fade_fused);                                              // :577-584 (+ :587-591 when fused)
         }
         if (!fade_fused) {
             const fs_grid g = grid_of(c, 0);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fs_k_diffuse_n": (_i, [_G, _p, _p, _i, _sz, _f, _f, _i, C.POINTER(_i), _p]),
     "fs_k_advect": (_i, [_G, _p, _p, _p, _p, _i, _sz, _f, _p, _p]),
     "fs_k_advect_fade": (_i, [_G, _p, _p, _p, _p, _i, _sz, _f, _f, _p, _p]),
+    "fs_k_advect_both": (_i, [_G, _p, _p, _p, _p, _p, _p, _sz, _f, _i, _f, _p, _p]),
     "fs_k_divergence": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_pressureSolve": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_pressureSolve_n": (_i, [_G, _p, _p, _p, _i, _i, C.POINTER(_i), _p]),

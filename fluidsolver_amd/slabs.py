@@ -116,6 +116,11 @@ class HipBackend:
         L.check(self.lib.fs_k_advect_fade(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(src), self._p(dst),
                                           src.shape[0], src.stride(0), dt, rate, C.c_void_p(err.data_ptr()), self._s()))
 
+    def advect_both(self, g, vel, vel_out, dye, dye_out, dt, rate, err):
+        L.check(self.lib.fs_k_advect_both(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(vel_out, 0),
+                                          self._p(vel_out, 1), self._p(dye), self._p(dye_out), dye.stride(0), dt, 1, rate,
+                                          C.c_void_p(err.data_ptr()), self._s()))
+
     def fade(self, g, dye, rate):
         L.check(self.lib.fs_k_fadeDensity(C.byref(g), self._p(dye), dye.shape[0], dye.stride(0), rate, self._s()))
 
@@ -424,6 +429,9 @@ class SlabSolver:
             V["dye"] = 0
             return
         fused = hasattr(self.be, "advect_fade")
+        # both advections of the same rows in one pass: pays only when a plane of the slab outgrows the Infinity Cache
+        both = (fused and hasattr(self.be, "advect_both")
+                and self.pitch * (self.H // self.world) * 4.0 >= 256.0 * 1024 * 1024)
         # overlap: the advected velocity is also computed on the ghost rows the next frame's chain
         # consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
         adv = max(0, min(need_v0, self.G - h)) if (multi and self.overlap) else 0
@@ -434,8 +442,11 @@ class SlabSolver:
             i1 = self.r1 - (h if self.r1 < self.H else 0)
             old, new = self.f["vel"], self.f["vel_t"]
             # interior rows: no tap of their backtrace leaves the owned rows    :550-558, :577-591
-            self._advect_rows("vel", old, i0, i1, False)
-            self._advect_rows("dye", new, i0, i1, fused)
+            if both:
+                self._advect_both_rows(i0, i1)
+            else:
+                self._advect_rows("vel", old, i0, i1, False)
+                self._advect_rows("dye", new, i0, i1, fused)
             self._join("vel")
             self._advect_rows("vel", old, self.r0 - adv, i0, False)
             self._advect_rows("vel", old, i1, self.r1 + adv, False)
@@ -449,19 +460,30 @@ class SlabSolver:
             if multi:
                 self._ensure([("vel", h + adv), ("dye", h + ddn)])             # one batched round
                 self._join("dye")
-            self._advect_rows("vel", self.f["vel"], self.r0 - adv, self.r1 + adv, False)   # :550-558
-            self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
-            if multi:
-                V["vel"] = adv
-            if ddn:
-                self._sweeps("diffuse", "dye", N, h)                           # :562-574
-                self._need("dye", h)
-            self._advect_rows("dye", self.f["vel"], self.r0, self.r1, fused)   # :577-584 (+ :587-591 when fused)
+            if both and not multi and not ddn:
+                self._advect_both_rows(self.r0, self.r1)                       # :550-558 + :577-591 in one pass
+                self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
+            else:
+                self._advect_rows("vel", self.f["vel"], self.r0 - adv, self.r1 + adv, False)   # :550-558
+                self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
+                if multi:
+                    V["vel"] = adv
+                if ddn:
+                    self._sweeps("diffuse", "dye", N, h)                       # :562-574
+                    self._need("dye", h)
+                self._advect_rows("dye", self.f["vel"], self.r0, self.r1, fused)   # :577-584 (+ :587-591 when fused)
             self.f["dye"], self.f["dye_t"] = self.f["dye_t"], self.f["dye"]
         if not fused:
             self.be.fade(self.grid(0), self.f["dye"], float(self.fadeSpeed))   # :587-591
         if multi:
             V["dye"] = 0
+
+    def _advect_both_rows(self, yb, ye):
+        yb = max(yb, self.b0)
+        ye = max(yb, min(ye, self.b1))
+        g = L.Grid(self.W, self.H, self.pitch, self.b0, self.b1 - self.b0, yb, ye)
+        self.be.advect_both(g, self.f["vel"], self.f["vel_t"], self.f["dye"], self.f["dye_t"], float(self.deltaTime),
+                            float(self.fadeSpeed), self.err)
 
     def _advect_rows(self, name, vel, yb, ye, fade):
         """advect field `name` through `vel` on rows [yb, ye) (clipped to the buffer), into its partner."""

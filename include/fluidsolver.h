@@ -111,6 +111,13 @@ int fs_k_advect_fade(const fs_grid *g, const float *u, const float *v, const flo
                      int nplanes, size_t plane_stride, float deltaTime, float fadeRate,
                      int *err_flag, void *stream);
 
+/* Both advections of update() in one pass: the velocity by itself (Solver:550-558) into u_out/v_out, then the
+ * three dye planes through that NEW velocity (Solver:577-584), optionally followed by fadeDensity (:587-591).  Same
+ * bits as fs_k_advect(velocity) + fs_k_advect[_fade](dye); the advected velocity is not read back. */
+int fs_k_advect_both(const fs_grid *g, const float *u, const float *v, float *u_out, float *v_out,
+                     const float *dye, float *dye_out, size_t dye_stride, float deltaTime,
+                     int fade, float fadeRate, int *err_flag, void *stream);
+
 /* replaces kernel divergence, Shaders:162-181 */
 int fs_k_divergence(const fs_grid *g, const float *u, const float *v, float *div, void *stream);
 

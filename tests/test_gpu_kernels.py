@@ -602,3 +602,30 @@ def test_projection_with_cfl_on_a_row_range(lib, oracle, n):
     assert np.array_equal(got[:, :yb - y0], vel[:, y0:yb]) and np.array_equal(got[:, ye - y0:], vel[:, ye:y0 + rows])
     assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0][yb - y0:ye - y0], a[yb:ye])
     assert float(cfl.item()) == float(np.abs(e[1][yb:ye]).max())
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(600, 150)])
+@pytest.mark.parametrize("speed", [0.3, 6.0, 40.0])
+@pytest.mark.parametrize("fade", [0, 1])
+def test_both_advections_in_one_pass(lib, oracle, W, H, speed, fade):
+    """fs_k_advect_both == advect(velocity by itself) then advect(dye by the NEW velocity) [+ fadeDensity]
+    (Solver:550-591), bit for bit, for slow, fast and domain-crossing flows."""
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, stride, sync
+    from oracle_binding import full_grid
+    vel, den = rnd((2, H, W), 70, -speed, speed), rnd((3, H, W), 71, -1, 3)
+    g, og = grid(W, H), full_grid(W, H)
+    ev = np.zeros((2, H, W), F)
+    for c in range(2):
+        oracle.advect(og, vel[0], vel[1], vel[c], ev[c], 0.5)
+    ed = np.zeros((3, H, W), F)
+    for c in range(3):
+        oracle.advect(og, ev[0], ev[1], den[c], ed[c], 0.5)
+        if fade:
+            oracle.fadeDensity(og, ed[c], 0.002)
+    dv, dvo = dev_planes(vel), dev_planes(np.zeros((2, H, W), F))
+    dd, ddo = dev_planes(den), dev_planes(np.zeros((3, H, W), F))
+    ok(lib.fs_k_advect_both(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(dvo, 0), ptr(dvo, 1), ptr(dd), ptr(ddo), stride(dd), 0.5,
+                            fade, 0.002, None, stream()))
+    sync()
+    assert np.array_equal(host_planes(dvo, W), ev)
+    assert np.array_equal(host_planes(ddo, W), ed)

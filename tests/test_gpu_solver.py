@@ -80,6 +80,52 @@ def test_fused_and_unfused_frames_are_identical():
         assert np.array_equal(s.read_field(L.FIELD_VELOCITY), gold["vel_6"]), fuse
 
 
+@pytest.mark.parametrize("fuse", [1, 2, 3])
+def test_every_fusion_option_equals_the_unfused_frame(oracle, fuse):
+    """FS_OPT_FUSE 1 / 2 / 3 (fade into the dye advection; the projection in one loop) against 0 and the oracle,
+    at a size with interior and edge tiles and N spanning several launches."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W, H, params = 700, 330, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 23)
+    s = make_solver(W, H, params)
+    s.set_option(L.OPT_FUSE, fuse)
+    o = oracle.solver(W, H)
+    p = Params(*params)
+    for f in range(4):
+        pos, force, col = splat(W, H, 11 * f)
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, p.deltaTime)
+        s.update()
+        o.update(p)
+    assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY))
+    assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY))
+    assert np.array_equal(s.read_field(L.FIELD_PRESSURE), o.field(PRESSURE))
+
+
+def test_out_of_cache_plan_equals_the_unfused_frame():
+    """8192^2: a plane (256 MiB) is as big as the Infinity Cache, so fs_step advects velocity and dye in one pass and
+    keeps the projection in separate passes -- the opposite choices of the 3072^2 frame.  No oracle at this size:
+    the fused frame must equal the unfused one bit for bit."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    W = H = 8192
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 12)
+    out = []
+    for fuse in (0, 1):
+        s = make_solver(W, H, params)
+        s.set_option(L.OPT_FUSE, fuse)
+        for f in range(3):
+            for ptr in range(4):
+                pos, force, col = splat(W, H, 9 * f + 1, ptr, 4)
+                s.applyForce(pos, force, col)
+            s.update()
+        out.append((s.read_field(L.FIELD_VELOCITY), s.read_field(L.FIELD_DENSITY)))
+        s.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][0]).max() > 1.0
+
+
 def test_zero_state_stays_zero():
     from fluidsolver_amd import lib as L
     s = make_solver(300, 200, (1.5e-4, 1e-4, 0.5, 10.0, 0.002, 12))

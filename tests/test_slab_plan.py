@@ -39,6 +39,7 @@ class _Recorder:
     def fade(self, g, dye, rate): self._rec("fade", g)
     def advect(self, g, vel, src, dst, dt, err): self._rec("advect", g, src.shape[0])
     def advect_fade(self, g, vel, src, dst, dt, rate, err): self._rec("advect_fade", g, src.shape[0])
+    def advect_both(self, g, vel, vel_out, dye, dye_out, dt, rate, err): self._rec("advect_both", g, 5)
 
     def diffuse_n(self, g, a, b, n, visc, dt):
         self._rec("diffuse_n", g, n)
@@ -168,4 +169,7 @@ def test_overlap_plan_hides_both_rounds():
     assert f[7] == "advect_fade %d %d 3" % (r0, r0 + 7) and f[8] == "advect_fade %d %d 3" % (r1 - 7, r1)
     assert f[9] == "exchange_async dye:7"                       # frame 2 begins: dye halo under the chain
     assert f[10].startswith("vorticity %d %d" % (r0 - 82, r1 + 82))
+    # one GPU, 16384^2: a plane (1 GiB) outgrows the Infinity Cache -> both advections in one pass
+    one = NS.plan_dump(W, H, 1, 0, None, params, [0])
+    assert "advect_both 0 16384 5\n" in one and "advect_fade" not in one
     assert not any(x.startswith("exchange ") for x in f)
