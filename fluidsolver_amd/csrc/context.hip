@@ -352,7 +352,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
         if (fs::config_set_block_depth(-1, value)) { fs::set_error("block depth %d out of range 1..48", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
-    case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 3) ? value : 1; break;
+    case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 4) ? value : 1; break;
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:

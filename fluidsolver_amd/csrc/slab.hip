@@ -285,7 +285,7 @@ struct Planner {
         // N + 1 ghost rows of velocity for it (it has them whenever the capacity allows: need_v2 = N + 1).
         const double loop_rows = multi ? (double)(c->H / c->world + 2 * (N + 1)) : (double)c->H;   // the same on every rank
         const bool cache_resident = 3.0 * (double)c->pitch * loop_rows * sizeof(float) < 192.0 * 1024 * 1024;
-        const bool project_fused = (c->fuse == 3 || (c->fuse == 1 && cache_resident)) && N > 0 && (!multi || G >= N + 1);
+        const bool project_fused = (c->fuse >= 3 || (c->fuse == 1 && cache_resident)) && N > 0 && (!multi || G >= N + 1);
         const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
         if (!project_fused) {
             const fs_grid g = grid_of(c, dd);
@@ -357,11 +357,11 @@ struct Planner {
         const int ddn = (p.diffusion > 0.0f && N > 0) ? N : 0;
         hipStream_t st = c->stream;
         const size_t plane = c->plane;
-        const bool fade_fused = c->fuse == 1 || c->fuse == 2;
+        const bool fade_fused = c->fuse == 1 || c->fuse == 2 || c->fuse == 4;
         // both advections in one pass: no gain while a plane fits the Infinity Cache (572 vs 570 us per frame at
         // 3072^2: the advected velocity is read back from the cache anyway), -0.5 % at 16384^2
         // (profiles/r01_q_ab_fuse_*.log); so only when a plane of the slab is at least as big as the cache
-        const bool both_fused = c->fuse == 1 && (double)c->pitch * (double)(c->H / c->world) * sizeof(float) >= 256.0 * 1024 * 1024;
+        const bool both_fused = c->fuse == 4 || (c->fuse == 1 && (double)c->pitch * (double)(c->H / c->world) * sizeof(float) >= 256.0 * 1024 * 1024);
         // overlap: the advected velocity is also computed on the ghost rows the next frame's stencil
         // chain consumes (as far as the ghost capacity allows), from a velocity halo of h + adv rows
         const int adv = (multi && c->overlap) ? std::max(0, std::min(chain_needs().v0, G - h)) : 0;

@@ -101,6 +101,10 @@ class _Slab:
         L.check(self.lib.fs_slab_stats(self.ctx, st))
         return {"exchanges": st[0], "rows_sent": st[1], "frames": st[2], "redo": st[3], "tracers_received": st[4]}
 
+    def set_fuse(self, mode):
+        """FS_OPT_FUSE (every rank must agree): 1 = default size rules, 4 = every fusion at any size, 0 = none."""
+        L.check(self.lib.fs_set_option(self.ctx, L.OPT_FUSE, int(mode)), self.ctx)
+
     def set_profile(self, on):
         """FS_OPT_SLAB_PROFILE: time every wait of the kernels for halo rows (read with waits())."""
         L.check(self.lib.fs_set_option(self.ctx, L.OPT_SLAB_PROFILE, 1 if on else 0), self.ctx)

@@ -256,9 +256,11 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), both loops */
        FS_OPT_WITH_PARTICLES = 2, /* 1: fs_step also runs the tracer update (default 0) */
        FS_OPT_FUSE = 4,           /* fs_step fusions, same bits either way: 1 (default) = fadeDensity into the dye advection AND
-                                     subtractGradient into the last pressure launch; 2 = the first only; 3 = the second only; 0 = none */
+                                     the projection in one loop where each pays (size rules in DESIGN.md), both advections in one pass for
+                                     out-of-cache planes; 2 = fade only; 3 = projection loop only, at any size; 4 = every fusion at any
+                                     size (tests); 0 = none */
        FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* fs_config_set/get only: depth of the pressure loop, default 10 */
-       FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */           /* 1 (default): fs_step fuses fadeDensity into the dye advection pass */
+       FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */
        FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */

@@ -111,6 +111,35 @@ def test_local_group_equals_single_gpu_context_at_size(mode):
         s.close()
 
 
+@pytest.mark.parametrize("fuse", [0, 4])
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_plans_with_every_fusion_forced_or_off(oracle_omp, world, fuse):
+    """The big-grid choices of the slab plan (both advections of the interior rows in one pass) and the no-fusion
+    plan, forced at a test size with FS_OPT_FUSE 4 / 0: still the oracle's bits."""
+    import test_slabs as T
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    case = CASES["config2_physics"]
+    W, H, params, ghost, frames, fscale = case
+    g = LocalGroup(W, H, params, world, device=0, ghost=ghost, asynchronous=True, overlap=True)
+    try:
+        for sl in g.slabs:
+            sl.set_fuse(fuse)
+        for f in range(frames):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, 2)
+                g.add_force(pos, (force[0] * F(fscale), force[1] * F(fscale)), col)
+            g.update()
+        g.sync()
+        if "config2_physics" not in _REF:
+            _REF["config2_physics"] = T._reference(case)
+        rvel, rdye, rprs = _REF["config2_physics"]
+        assert np.array_equal(g.field("vel"), rvel) and np.array_equal(g.field("dye"), rdye)
+        assert np.array_equal(g.field("p"), rprs)
+    finally:
+        g.close()
+
+
 def test_wrong_halo_guess_is_replanned():
     """Overlap mode guesses the advection halo from the previous frame.  A splat 40x stronger than the
     last one makes the guess too small: the advection must be planned again with the true depth (counted

@@ -80,9 +80,10 @@ def test_fused_and_unfused_frames_are_identical():
         assert np.array_equal(s.read_field(L.FIELD_VELOCITY), gold["vel_6"]), fuse
 
 
-@pytest.mark.parametrize("fuse", [1, 2, 3])
+@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
 def test_every_fusion_option_equals_the_unfused_frame(oracle, fuse):
-    """FS_OPT_FUSE 1 / 2 / 3 (fade into the dye advection; the projection in one loop) against 0 and the oracle,
+    """FS_OPT_FUSE 1 / 2 / 3 / 4 (fade into the dye advection; the projection in one loop; both advections in one
+    pass, forced at this small size by 4) against the oracle,
     at a size with interior and edge tiles and N spanning several launches."""
     from fluidsolver_amd import lib as L
     from fluidsolver_amd.script import splat
