@@ -182,21 +182,43 @@ def config4_extra(world, rank, local_rank, dist, frames=10, warm=4):
         s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
         step = lambda f: s.frame(f, n_pointers=8)   # noqa: E731
         sync = lambda: (s.sync(), torch.cuda.synchronize(), dist.barrier())   # noqa: E731
-    for f in range(warm):
-        step(f)
-    sync()
-    t0 = time.perf_counter()
-    for f in range(warm, warm + frames):
-        step(f)
-    sync()
-    el = time.perf_counter() - t0
+    def timed(f0):
+        for f in range(f0, f0 + warm):
+            step(f)
+        sync()
+        t0 = time.perf_counter()
+        for f in range(f0 + warm, f0 + warm + frames):
+            step(f)
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     out = {"grid": [W, H], "frames": frames, "pointers": 8}
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    if world == 1:
+        el = timed(0)
+    else:
+        # both slab plans, with every wait for halo rows timed (the event records cost ~1 us per join)
+        s.set_profile(True)
+        per_plan = {}
+        for k, mode in enumerate((0, 1)):
+            s.set_overlap(mode)
+            s.waits()
+            e = timed(k * (warm + frames))
+            w = s.waits()
+            wt = torch.tensor([w["vel_ms"], w["dye_ms"], w["blocking_ms"]], dtype=torch.float64)
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            n = float(warm + frames)
+            per_plan["overlap" if mode else "plain"] = {
+                "ms_per_frame": e * 1e3 / frames,
+                "exposed_wait_us_per_frame": {"velocity_halo": float(wt[0]) * 1e3 / n, "dye_halo": float(wt[1]) * 1e3 / n,
+                                              "blocking_exchanges": float(wt[2]) * 1e3 / n}}
+        el = min(v["ms_per_frame"] for v in per_plan.values()) * frames / 1e3
         st = s.stats
-        out.update(last_advect_halo=s.last_halo, advection_replans=st["redo"],
+        out.update(plans=per_plan, last_advect_halo=s.last_halo, advection_replans=st["redo"],
                    halo_rows_sent_per_frame=st["rows_sent"] / float(max(1, st["frames"])))
     s.close()
     out.update(ms_per_frame=el * 1e3 / frames, frames_per_s=frames / el,
