@@ -25,8 +25,8 @@ CASES = {
     "config1_256": dict(W=256, H=256, frames=1, params=(1.5e-4, 0.0, 0.5, 0.0, 0.002, 20), radius=5.0,
                         fixed_splat=((128.0, 128.0), (24.0, 0.0), (100.0, 0.0, 0.0)), save_at=(1,)),
     # config-2 physics (N=40, vorticity 10) on a small grid, scripted Lissajous splats
-    "script_64": dict(W=64, H=64, frames=10, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), radius=5.0,
-                      save_at=(1, 10)),
+    "script_64": dict(W=64, H=64, frames=100, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 40), radius=5.0,
+                      save_at=(1, 10, 100)),
     # "Smoke" preset (dye diffusion on), non-square grid whose width is not a multiple of 4
     "smoke_50x38": dict(W=50, H=38, frames=6, params=(0.00005, 0.00001, 0.4, 10.0, 0.008, 15), radius=4.0,
                         save_at=(6,)),
