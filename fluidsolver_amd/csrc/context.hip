@@ -68,6 +68,7 @@ using namespace fs;
 
 static void drop_graphs(fs_ctx *c)
 {
+    c->stable_frames = 0;
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graphs_after.clear();
@@ -400,8 +401,12 @@ int fs_step(fs_ctx *c)
         TRY(c, fs::run_frame(c));
         return FS_OK;
     }
-    if (!c->use_graph) {
+    // Scalars are baked into the recorded kernel nodes, so a change of parameters invalidates the graphs.  A host
+    // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
+    // host time) until the parameters have stayed put for two frames, and only then is a graph recorded again.
+    if (!c->use_graph || c->stable_frames < 2) {
         TRY(c, fs::run_frame(c));
+        c->stable_frames += 1;
         return FS_OK;
     }
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph

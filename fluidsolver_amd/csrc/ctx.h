@@ -102,6 +102,7 @@ struct fs_ctx {
     int halo_hist[4] = {-1, -1, -1, -1};   // advection halos the last frames really needed (-1: unknown), newest first
     fs_params params{};
     int use_graph = 1;
+    int stable_frames = 0;              // frames since the parameters / options last changed (graphs are recorded once they settle)
     int with_particles = 0;
     int fuse = 1;
     bool p_zero = false;                // planner state: pressure iterate is implicitly 0

@@ -127,6 +127,30 @@ def test_out_of_cache_plan_equals_the_unfused_frame():
     assert np.abs(out[0][0]).max() > 1.0
 
 
+def test_parameters_dragged_every_frame(oracle):
+    """A host dragging sliders changes fs_params every frame (graphs would be re-recorded each time: frames run
+    eagerly until the parameters settle), then leaves them alone (graph replay): every frame equals the oracle."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, VELOCITY, Params
+    W, H = 200, 136
+    s = make_solver(W, H, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 12))
+    o = oracle.solver(W, H)
+    for f in range(12):
+        if f < 7:   # the drag: viscosity, vorticity strength and iteration count all move
+            s.viscosity = 1.5e-4 * (1 + f)
+            s.vorticityStrength = 10.0 + f
+            s.solverIterations = 12 + (f % 3)
+        p = Params(s.viscosity, 0.0, 0.5, s.vorticityStrength, 0.002, s.solverIterations)
+        pos, force, col = splat(W, H, 9 * f)
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, p.deltaTime)
+        s.update()
+        o.update(p)
+        assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY)), f
+    assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY))
+
+
 def test_zero_state_stays_zero():
     from fluidsolver_amd import lib as L
     s = make_solver(300, 200, (1.5e-4, 1e-4, 0.5, 10.0, 0.002, 12))
