@@ -384,3 +384,14 @@ def test_particle_line_vertices_kat(oracle):
     xy, _ = oracle.particle_lines(np.array([0.0, 800.0], F), np.array([0.0, 600.0], F), np.zeros(2, F), np.zeros(2, F),
                                   np.ones(2, F), (800.0, 600.0), 1.0)
     assert np.array_equal(xy[:, 2:], np.array([[-1.0, 1.0], [1.0, -1.0]], F))
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """The oracle's kernels, slab row ranges, solver state and tracer functions under AddressSanitizer and
+    UndefinedBehaviorSanitizer (host code only): `make -C oracle sanitize` must exit 0."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "sanitize_check ok" in out.stdout
