@@ -49,6 +49,10 @@ struct Step {
 
 void slab_rows(int H, int world, int rank, int *r0, int *r1);
 
+// p + n, except that a plan-only context has no buffers: null stays null (null + n is undefined behaviour)
+template <class T>
+inline T *off(T *p, size_t n) { return p ? p + n : p; }
+
 }  // namespace fs
 
 // Transport of the halo exchange.  kind 1 = RCCL (one process per GPU, ncclSend/ncclRecv over xGMI).

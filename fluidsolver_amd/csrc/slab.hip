@@ -176,7 +176,7 @@ struct Planner {
                 const int pz = c->p_zero ? 1 : 0;
                 c->p_zero = false;
                 const float *div = c->f[F_DIV].p();
-                float *u = c->f[F_VEL].p(), *v = u + c->plane;
+                float *u = c->f[F_VEL].p(), *v = off(u, c->plane);
                 if (with_gradient) {
                     float *dw = c->f[F_DIV].p();
                     compute("project_n", g, n, [=]() {                                // Solver:522-547
@@ -211,7 +211,7 @@ struct Planner {
         Field &F = c->f[fi];
         const fs_grid g = grid_rows(yb, ye);
         const bool vel_done = fi != F_VEL;   // the dye is traced through the advected velocity (Solver:577-582)
-        const float *u = vel_done ? c->f[F_VEL].p() : F.p(), *v = u + c->plane;
+        const float *u = vel_done ? c->f[F_VEL].p() : F.p(), *v = off(u, c->plane);
         const float *src = F.p();
         float *dst = F.t();
         const int np = F.np;
@@ -229,8 +229,8 @@ struct Planner {
     {
         Field &V = c->f[F_VEL], &D = c->f[F_DYE];
         const fs_grid g = grid_rows(yb, ye);
-        const float *u = V.p(), *v = u + c->plane, *dye = D.p();
-        float *uo = V.t(), *vo = uo + c->plane, *dyo = D.t();
+        const float *u = V.p(), *v = off(u, c->plane), *dye = D.p();
+        float *uo = V.t(), *vo = off(uo, c->plane), *dyo = D.t();
         const size_t plane = c->plane;
         const float dt = c->params.deltaTime, fr = c->params.fadeSpeed;
         int *err = c->err_flag;
@@ -264,13 +264,13 @@ struct Planner {
             const int dw = multi ? std::min(need_v1 + 1, eff(F_VEL) - 1) : 0;
             {
                 const fs_grid g = grid_of(c, dw);
-                float *u = V.p(), *v = u + plane, *w = c->f[F_VORT].p();
+                float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
                 compute("vorticity", g, 0, [=]() { return fs_k_calculateVorticity(&g, u, v, w, st); });   // :488-491
             }
             const int dv = multi ? std::min(std::min(need_v1, dw - 1), eff(F_VEL)) : 0;
             {
                 const fs_grid g = grid_of(c, dv);
-                float *u = V.p(), *v = u + plane, *w = c->f[F_VORT].p();
+                float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
                 const float strength = p.vorticityStrength;
                 compute("applyVorticity", g, 0, [=]() { return fs_k_applyVorticity(&g, w, u, v, strength, dt, st); });   // :494-501
             }
@@ -289,7 +289,7 @@ struct Planner {
         const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
         if (!project_fused) {
             const fs_grid g = grid_of(c, dd);
-            float *u = V.p(), *v = u + plane, *d = c->f[F_DIV].p();
+            float *u = V.p(), *v = off(u, plane), *d = c->f[F_DIV].p();
             compute("divergence", g, 0, [=]() { return fs_k_divergence(&g, u, v, d, st); });              // :522-525
         }
         if (multi) c->f[F_DIV].valid = dd;
@@ -303,7 +303,7 @@ struct Planner {
         if (project_fused && multi) {
             const fs_grid g = grid_of(c, 0);
             Field &P = c->f[F_P];
-            float *u = V.p(), *v = u + plane, *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = c->cfl_dev;
+            float *u = V.p(), *v = off(u, plane), *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = c->cfl_dev;
             compute("project_n_cfl", g, N, [=]() {                                    // :522-547 + the CFL bound
                 hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
                 if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
@@ -325,7 +325,7 @@ struct Planner {
         if (!grad_fused) need(F_P, 1);
         {
             const fs_grid g = grid_of(c, 0);
-            float *u = V.p(), *v = u + plane, *pp = c->f[F_P].p();
+            float *u = V.p(), *v = off(u, plane), *pp = c->f[F_P].p();
             if (grad_fused) {
                 // done
             } else if (!multi) {
@@ -415,7 +415,7 @@ struct Planner {
         // render, :594-623
         {
             const fs_grid g = grid_of(c, 0);
-            float *u = c->f[F_VEL].p(), *v = u + plane, *d = c->f[F_DYE].p(), *w = c->f[F_VORT].p(), *disp = c->display;
+            float *u = c->f[F_VEL].p(), *v = off(u, plane), *d = c->f[F_DYE].p(), *w = c->f[F_VORT].p(), *disp = c->display;
             const float br = p.brightness;
             switch (p.displayMode) {
             case FS_DISPLAY_DENSITY:
@@ -438,7 +438,7 @@ struct Planner {
         }
         if (c->with_particles && c->n_particles > 0 && !multi) {                      // MetalView.swift:155 -> Part:242
             const fs_grid g = grid_of(c, 0);
-            float *u = c->f[F_VEL].p(), *v = u + plane;
+            float *u = c->f[F_VEL].p(), *v = off(u, plane);
             const fs_particle_params pp = c->pparams;
             const long n = c->n_particles;
             float *a0 = c->part[0], *a1 = c->part[1], *a2 = c->part[2], *a3 = c->part[3], *a4 = c->part[4],

@@ -173,3 +173,21 @@ def test_overlap_plan_hides_both_rounds():
     one = NS.plan_dump(W, H, 1, 0, None, params, [0])
     assert "advect_both 0 16384 5\n" in one and "advect_fade" not in one
     assert not any(x.startswith("exchange ") for x in f)
+
+
+def test_planner_host_code_is_clean_under_asan_and_ubsan(tmp_path):
+    """The library's host code that plans frames, compiled with hipcc and ASan + UBSan on the HOST side only
+    (the device code is untouched; no GPU is needed: the plan dump runs on plan-only contexts)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    csrc = os.path.join(root, "fluidsolver_amd", "csrc")
+    exe = str(tmp_path / "plan_check")
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O1", "-g", "-std=c++17", "-ffp-contract=off",
+           "--offload-arch=gfx950", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+           "-Xarch_host", "-fno-sanitize-recover=undefined",
+           "-I", os.path.join(root, "include"), "-I", csrc, "-o", exe, os.path.join(HERE, "host_sanitize", "plan_check.cpp")]
+    cmd += [os.path.join(csrc, n) for n in ("passes.hip", "jacobi.hip", "context.hip", "slab.hip")] + ["-ldl"]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0 and "plan_check ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
