@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const floa
         float posy = (float)q.y - vy[j] * dt;
         posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
         posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
-        const int i0x = (int)floorf(posx);                        // :140
+        // (W = 1: the clamp range of :136 is empty and posx lands at -0.5; every cell is a boundary cell then and
+        // copies its input, the max() only keeps the unused taps inside the buffer)
+        const int i0x = max((int)floorf(posx), 0);                // :140
         int i0y = (int)floorf(posy);
         sx[j] = posx - (float)i0x;                                // :142
         sy[j] = posy - (float)i0y;
@@ -357,7 +359,9 @@ __device__ __forceinline__ bool backtrace4(const GK &g, const Quad &q, const flo
         float posy = (float)q.y - vy[j] * dt;
         posx = fminf(fmaxf(posx, 0.5f), (float)(unsigned)g.W - 1.5f);   // :136
         posy = fminf(fmaxf(posy, 0.5f), (float)(unsigned)g.H - 1.5f);   // :137
-        const int i0x = (int)floorf(posx);                        // :140
+        // (W = 1: the clamp range of :136 is empty and posx lands at -0.5; every cell is a boundary cell then and
+        // copies its input, the max() only keeps the unused taps inside the buffer)
+        const int i0x = max((int)floorf(posx), 0);                // :140
         int i0y = (int)floorf(posy);
         t.sx[j] = posx - (float)i0x;                              // :142
         t.sy[j] = posy - (float)i0y;

@@ -32,8 +32,8 @@ public final class FluidSolver {
     public private(set) var gridWidth: Int
     public private(set) var gridHeight: Int
     public var resolutionScale: Int = 1 { didSet { if resolutionScale != oldValue { reinitialize() } } }   // :89-96
-    public var scaledWidth: Int { gridWidth / max(1, resolutionScale) }      // :99-102
-    public var scaledHeight: Int { gridHeight / max(1, resolutionScale) }    // :103-106
+    public var scaledWidth: Int { max(32, gridWidth / max(1, resolutionScale)) }      // :99-102
+    public var scaledHeight: Int { max(32, gridHeight / max(1, resolutionScale)) }    // :103-106
 
     private var ctx: OpaquePointer?             // replaces device / commandQueue / library / 13 pipelines / 9 textures
     private let device: Int32

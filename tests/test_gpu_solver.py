@@ -127,6 +127,38 @@ def test_out_of_cache_plan_equals_the_unfused_frame():
     assert np.abs(out[0][0]).max() > 1.0
 
 
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 2), (3, 2), (1, 40), (40, 1), (4, 3), (257, 2), (2, 257), (65, 65)])
+def test_degenerate_grids_match_oracle(oracle, W, H):
+    """Grids with no interior at all (every cell is a boundary cell), one-cell-wide strips, sizes just past a
+    tile / pitch edge: whole frames with every stage on still equal the oracle bit for bit (and do not fault)."""
+    import ctypes as C
+    from fluidsolver_amd import lib as L
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    params = (1.5e-4, 0.00001, 0.5, 10.0, 0.002, 11)
+    lib = L.load()
+    ctx = C.c_void_p()               # the C ABI directly: the FluidSolver mirror never goes below 32 x 32 (Solver:99-106)
+    L.check(lib.fs_create(W, H, 0, 0, C.byref(ctx)))
+    try:
+        fp = L.Params(*params[:5], params[5], L.DISPLAY_NONE, 0.06)
+        L.check(lib.fs_set_params(ctx, C.byref(fp)), ctx)
+        o = oracle.solver(W, H)
+        p = Params(*params)
+        for f in range(6):           # enough frames to leave the eager start and replay the recorded graph
+            pos, force, col = (W * 0.4 + f, H * 0.6), (7.0, -3.0 - f), (10.0, 20.0, 30.0)
+            rgba = (C.c_float * 4)(col[0], col[1], col[2], 0.0)
+            L.check(lib.fs_add_force(ctx, pos[0], pos[1], force[0], force[1], rgba, 5.0, 0.5), ctx)
+            o.add_force(pos, force, col, 5.0, p.deltaTime)
+            L.check(lib.fs_step(ctx), ctx)
+            o.update(p)
+        L.check(lib.fs_sync(ctx), ctx)
+        for fid, oid in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+            got = np.empty((L.FIELD_PLANES[fid], H, W), F)
+            L.check(lib.fs_read_field(ctx, fid, got.ctypes.data_as(C.c_void_p), got.nbytes), ctx)
+            assert np.array_equal(got, o.field(oid)), (fid, got, o.field(oid))
+    finally:
+        lib.fs_destroy(ctx)
+
+
 def test_parameters_dragged_every_frame(oracle):
     """A host dragging sliders changes fs_params every frame (graphs would be re-recorded each time: frames run
     eagerly until the parameters settle), then leaves them alone (graph replay): every frame equals the oracle."""
