@@ -166,6 +166,51 @@ __device__ __forceinline__ void vort_force(float l, float r, float t, float b, f
     vv = vv + (sc * (-gx)) * dt;
 }
 
+// calculateVorticity + applyVorticity in one pass, for planes that outgrow the Infinity Cache: every vorticity value
+// a cell needs (its own and its four neighbours') is recomputed from u, v -- the re-read rows come out of L2 -- so
+// the vorticity plane is neither written nor read back (32 -> 16 B/cell of HBM traffic).  The confinement force
+// needs the OLD velocity of the neighbours, so the result goes to the ping-pong partner, not in place.  Same
+// expression per value, hence the same bits as the two kernels.
+__device__ __forceinline__ float curl_at(const GK &g, int x, int y, float u_b, float u_t, float v_r, float v_l)
+{
+    return is_boundary(g, x, y) ? 0.0f : (u_b - u_t) - (v_r - v_l);           // Shaders:262-273
+}
+__global__ __launch_bounds__(256) void k_vorticity_apply(GK g, int yb, int ye, const float *__restrict__ u,
+                                                         const float *__restrict__ v, float *__restrict__ uo,
+                                                         float *__restrict__ vo, float strength, float dt)
+{
+    Quad q = quad_of_thread(g, yb, ye);
+    if (!q.ok) return;
+    const int x = q.x, y = q.y;
+    const int ym1 = clamp_row(g, y - 1), ym2 = clamp_row(g, y - 2), yp1 = clamp_row(g, y + 1), yp2 = clamp_row(g, y + 2);
+    const float4 u0 = ld4(u + row_off(g, y) + x), um2 = ld4(u + row_off(g, ym2) + x), up2 = ld4(u + row_off(g, yp2) + x);
+    const RowN um1 = load_row_nb(u, g, x, ym1), up1 = load_row_nb(u, g, x, yp1);
+    const RowN vm1 = load_row_nb(v, g, x, ym1), v0 = load_row_nb(v, g, x, y), vp1 = load_row_nb(v, g, x, yp1);
+    const float *vrow = v + row_off(g, y);
+    const float v_ll = x > 1 ? vrow[x - 2] : 0.0f, v_rr = x + 5 < g.pitch ? vrow[x + 5] : 0.0f;
+    // vorticity of row y at columns x-1 .. x+4
+    const float wl = curl_at(g, x - 1, y, up1.l, um1.l, v0.c.x, v_ll);
+    const float w0 = curl_at(g, x + 0, y, up1.c.x, um1.c.x, v0.c.y, v0.l);
+    const float w1 = curl_at(g, x + 1, y, up1.c.y, um1.c.y, v0.c.z, v0.c.x);
+    const float w2 = curl_at(g, x + 2, y, up1.c.z, um1.c.z, v0.c.w, v0.c.y);
+    const float w3 = curl_at(g, x + 3, y, up1.c.w, um1.c.w, v0.r, v0.c.z);
+    const float wr = curl_at(g, x + 4, y, up1.r, um1.r, v_rr, v0.c.w);
+    // vorticity of rows y-1 and y+1 at columns x .. x+3
+    const float4 vl_t = lefts(vm1), vr_t = rights(vm1), vl_b = lefts(vp1), vr_b = rights(vp1);
+    const float t0 = curl_at(g, x + 0, y - 1, u0.x, um2.x, vr_t.x, vl_t.x), t1 = curl_at(g, x + 1, y - 1, u0.y, um2.y, vr_t.y, vl_t.y);
+    const float t2 = curl_at(g, x + 2, y - 1, u0.z, um2.z, vr_t.z, vl_t.z), t3 = curl_at(g, x + 3, y - 1, u0.w, um2.w, vr_t.w, vl_t.w);
+    const float b0 = curl_at(g, x + 0, y + 1, up2.x, u0.x, vr_b.x, vl_b.x), b1 = curl_at(g, x + 1, y + 1, up2.y, u0.y, vr_b.y, vl_b.y);
+    const float b2 = curl_at(g, x + 2, y + 1, up2.z, u0.z, vr_b.z, vl_b.z), b3 = curl_at(g, x + 3, y + 1, up2.w, u0.w, vr_b.w, vl_b.w);
+    float4 uu = u0, vv = v0.c;
+    if (!is_boundary(g, x + 0, y)) vort_force(wl, w1, t0, b0, w0, strength, dt, uu.x, vv.x);
+    if (!is_boundary(g, x + 1, y)) vort_force(w0, w2, t1, b1, w1, strength, dt, uu.y, vv.y);
+    if (!is_boundary(g, x + 2, y)) vort_force(w1, w3, t2, b2, w2, strength, dt, uu.z, vv.z);
+    if (!is_boundary(g, x + 3, y)) vort_force(w2, wr, t3, b3, w3, strength, dt, uu.w, vv.w);
+    const size_t o = row_off(g, y) + x;
+    st4(uo + o, uu);
+    st4(vo + o, vv);
+}
+
 __global__ __launch_bounds__(256) void k_apply_vorticity(GK g, int yb, int ye, const float *__restrict__ w,
                                                          float *__restrict__ u, float *__restrict__ v,
                                                          float strength, float dt)
@@ -682,6 +727,19 @@ int fs_k_applyVorticity(const fs_grid *g, const float *vort, float *u, float *v,
     hipLaunchKernelGGL(k_apply_vorticity, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, vort, u, v,
                        strength, deltaTime);
     FS_LAUNCH_CHECK("k_apply_vorticity");
+    return FS_OK;
+}
+
+int fs_k_vorticity_apply(const fs_grid *g, const float *u, const float *v, float *u_out, float *v_out, float strength,
+                         float deltaTime, void *stream)
+{
+    CHECK_GRID(g);
+    REQUIRE(u && v && u_out && v_out, "null pointer");
+    REQUIRE(u != u_out && v != v_out, "the confinement force needs the old velocity of the neighbours: not in place");
+    EMPTY_OK(g);
+    hipLaunchKernelGGL(k_vorticity_apply, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v, u_out, v_out,
+                       strength, deltaTime);
+    FS_LAUNCH_CHECK("k_vorticity_apply");
     return FS_OK;
 }
 

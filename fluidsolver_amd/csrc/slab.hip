@@ -262,17 +262,29 @@ struct Planner {
         if (vort_on) {                                                                // :486-502
             need(F_VEL, need_v0);
             const int dw = multi ? std::min(need_v1 + 1, eff(F_VEL) - 1) : 0;
-            {
-                const fs_grid g = grid_of(c, dw);
-                float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
-                compute("vorticity", g, 0, [=]() { return fs_k_calculateVorticity(&g, u, v, w, st); });   // :488-491
-            }
             const int dv = multi ? std::min(std::min(need_v1, dw - 1), eff(F_VEL)) : 0;
-            {
+            // out-of-cache planes: both passes in one, the vorticity plane never touches memory (it is then not
+            // available to read back or display, so not in the vorticity display mode)
+            const bool big = (double)c->pitch * (double)(c->H / c->world) * sizeof(float) >= 256.0 * 1024 * 1024;
+            if ((c->fuse == 4 || (c->fuse == 1 && big)) && p.displayMode != FS_DISPLAY_VORTICITY) {
                 const fs_grid g = grid_of(c, dv);
-                float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
+                const float *u = V.p(), *v = off(u, plane);
+                float *uo = V.t(), *vo = off(uo, plane);
                 const float strength = p.vorticityStrength;
-                compute("applyVorticity", g, 0, [=]() { return fs_k_applyVorticity(&g, w, u, v, strength, dt, st); });   // :494-501
+                compute("vorticity_apply", g, 0, [=]() { return fs_k_vorticity_apply(&g, u, v, uo, vo, strength, dt, st); });   // :486-502
+                V.cur ^= 1;
+            } else {
+                {
+                    const fs_grid g = grid_of(c, dw);
+                    float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
+                    compute("vorticity", g, 0, [=]() { return fs_k_calculateVorticity(&g, u, v, w, st); });   // :488-491
+                }
+                {
+                    const fs_grid g = grid_of(c, dv);
+                    float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();
+                    const float strength = p.vorticityStrength;
+                    compute("applyVorticity", g, 0, [=]() { return fs_k_applyVorticity(&g, w, u, v, strength, dt, st); });   // :494-501
+                }
             }
             if (multi) { c->f[F_VORT].valid = dw; V.valid = dv; }
         }

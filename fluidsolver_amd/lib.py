@@ -74,6 +74,7 @@ SIGNATURES = {
     "fs_k_pressureSolve_n_gradient": (_i, [_G, _p, _p, _p, _i, _i, _p, _p, C.POINTER(_i), _p]),
     "fs_k_calculateVorticity": (_i, [_G, _p, _p, _p, _p]),
     "fs_k_applyVorticity": (_i, [_G, _p, _p, _p, _f, _f, _p]),
+    "fs_k_vorticity_apply": (_i, [_G, _p, _p, _p, _p, _f, _f, _p]),
     "fs_k_fadeDensity": (_i, [_G, _p, _i, _sz, _f, _p]),
     "fs_k_clear": (_i, [_G, _p, _i, _sz, _p]),
     "fs_k_renderDensity": (_i, [_G, _p, _sz, _i, _p, _sz, _f, _p]),

@@ -70,6 +70,10 @@ class HipBackend:
     def vorticity(self, g, vel, w):
         L.check(self.lib.fs_k_calculateVorticity(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(w), self._s()))
 
+    def vorticity_apply(self, g, vel, vel_out, strength, dt):
+        L.check(self.lib.fs_k_vorticity_apply(C.byref(g), self._p(vel, 0), self._p(vel, 1), self._p(vel_out, 0),
+                                              self._p(vel_out, 1), strength, dt, self._s()))
+
     def applyVorticity(self, g, w, vel, strength, dt):
         L.check(self.lib.fs_k_applyVorticity(C.byref(g), self._p(w), self._p(vel, 0), self._p(vel, 1), strength, dt,
                                              self._s()))
@@ -364,10 +368,17 @@ class SlabSolver:
         if vort_on:                                                            # :486-502
             self._need("vel", need_v0)
             dw = min(need_v1 + 1, eff("vel") - 1) if multi else 0
-            self.be.vorticity(self.grid(dw), self.f["vel"], self.f["vort"])    # :488-491
             dv = min(need_v1, dw - 1, eff("vel")) if multi else 0
-            self.be.applyVorticity(self.grid(dv), self.f["vort"], self.f["vel"],
-                                   float(self.vorticityStrength), dt)          # :494-501
+            # out-of-cache planes: both passes in one, out of place, the vorticity plane never touches memory
+            big = self.pitch * (self.H // self.world) * 4.0 >= 256.0 * 1024 * 1024
+            if big and hasattr(self.be, "vorticity_apply"):
+                self.be.vorticity_apply(self.grid(dv), self.f["vel"], self.f["vel_t"],
+                                        float(self.vorticityStrength), dt)     # :486-502
+                self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
+            else:
+                self.be.vorticity(self.grid(dw), self.f["vel"], self.f["vort"])    # :488-491
+                self.be.applyVorticity(self.grid(dv), self.f["vort"], self.f["vel"],
+                                       float(self.vorticityStrength), dt)          # :494-501
             if multi:
                 V["vort"], V["vel"] = dw, dv
         if visc_on and N > 0:                                                  # :505-518

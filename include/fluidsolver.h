@@ -158,6 +158,12 @@ int fs_k_calculateVorticity(const fs_grid *g, const float *u, const float *v, fl
 int fs_k_applyVorticity(const fs_grid *g, const float *vort, float *u, float *v,
                         float strength, float deltaTime, void *stream);
 
+/* calculateVorticity + applyVorticity (Solver:486-502) in one pass on rows [yb,ye), OUT OF PLACE (u_out, v_out must
+ * not alias u, v); the vorticity plane is neither written nor read.  Same bits in the velocity as the two kernels.
+ * Needs two rows of velocity beyond [yb,ye) in the buffer (clipped to the domain). */
+int fs_k_vorticity_apply(const fs_grid *g, const float *u, const float *v, float *u_out, float *v_out,
+                         float strength, float deltaTime, void *stream);
+
 /* replaces kernel fadeDensity, Shaders:326-334 (buffer 0 fadeRate) */
 int fs_k_fadeDensity(const fs_grid *g, float *d, int nplanes, size_t plane_stride,
                      float fadeRate, void *stream);
@@ -256,8 +262,8 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_BLOCK_DEPTH = 1,    /* sweeps fused per Jacobi launch (temporal blocking), both loops */
        FS_OPT_WITH_PARTICLES = 2, /* 1: fs_step also runs the tracer update (default 0) */
        FS_OPT_FUSE = 4,           /* fs_step fusions, same bits either way: 1 (default) = fadeDensity into the dye advection AND
-                                     the projection in one loop where each pays (size rules in DESIGN.md), both advections in one pass for
-                                     out-of-cache planes; 2 = fade only; 3 = projection loop only, at any size; 4 = every fusion at any
+                                     the projection in one loop where each pays (size rules in DESIGN.md), both advections in one pass and
+                                     curl + confinement in one pass for out-of-cache planes; 2 = fade only; 3 = projection loop only, at any size; 4 = every fusion at any
                                      size (tests); 0 = none */
        FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* fs_config_set/get only: depth of the pressure loop, default 10 */
        FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */

@@ -13,7 +13,7 @@ for f in range(30):
     pos, force, col = splat(W, H, f); s.applyForce(pos, force, col); s.update()
 ms = C.c_float()
 for rep in range(3):
-    for mode, name in ((1, "fade + gradient fused"), (2, "fade fused only"), (0, "nothing fused")):
+    for mode, name in ((1, "default size rules"), (2, "fade fused only"), (0, "nothing fused")):
         s.set_option(L.OPT_FUSE, mode)
         for _ in range(4): s.update()
         s.sync()

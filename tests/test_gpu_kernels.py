@@ -629,3 +629,33 @@ def test_both_advections_in_one_pass(lib, oracle, W, H, speed, fade):
     sync()
     assert np.array_equal(host_planes(dvo, W), ev)
     assert np.array_equal(host_planes(ddo, W), ed)
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(600, 150), (1, 9), (2, 2)])
+def test_vorticity_and_confinement_in_one_pass(lib, oracle, W, H):
+    """fs_k_vorticity_apply == calculateVorticity + applyVorticity (Solver:486-502), out of place, bit for bit --
+    on the whole grid and on a row range of a slab-like buffer."""
+    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
+    from oracle_binding import full_grid
+    vel = rnd((2, H, W), 81, -3, 3)
+    vel[:, H // 2, : W // 2] = 0.0        # zero-gradient cells exercise the +1e-5 guard
+    og = full_grid(W, H)
+    w = np.zeros((H, W), F)
+    oracle.calculateVorticity(og, vel[0], vel[1], w)
+    e = vel.copy()
+    oracle.applyVorticity(og, w, e[0], e[1], 10.0, 0.5)
+    g = grid(W, H)
+    dv, do = dev_planes(vel), dev_planes(rnd((2, H, W), 82))
+    ok(lib.fs_k_vorticity_apply(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(do, 0), ptr(do, 1), 10.0, 0.5, stream()))
+    sync()
+    assert np.array_equal(host_planes(do, W), e)
+    assert np.array_equal(host_planes(dv, W), vel)                 # the input is left alone
+    assert lib.fs_k_vorticity_apply(C.byref(g), ptr(dv, 0), ptr(dv, 1), ptr(dv, 0), ptr(dv, 1), 10.0, 0.5, stream()) == -1
+    if H >= 12:
+        y0, rows = 2, H - 4
+        yb, ye = y0 + 2, y0 + rows - 2
+        g2 = grid(W, H, y0=y0, rows=rows, yb=yb, ye=ye)
+        dv2, do2 = dev_planes(vel[:, y0:y0 + rows]), dev_planes(np.zeros((2, rows, W), F))
+        ok(lib.fs_k_vorticity_apply(C.byref(g2), ptr(dv2, 0), ptr(dv2, 1), ptr(do2, 0), ptr(do2, 1), 10.0, 0.5, stream()))
+        sync()
+        assert np.array_equal(host_planes(do2, W)[:, yb - y0:ye - y0], e[:, yb:ye])

@@ -33,6 +33,7 @@ class _Recorder:
 
     def vorticity(self, g, vel, w): self._rec("vorticity", g)
     def applyVorticity(self, g, w, vel, s, dt): self._rec("applyVorticity", g)
+    def vorticity_apply(self, g, vel, vel_out, s, dt): self._rec("vorticity_apply", g)
     def divergence(self, g, vel, div): self._rec("divergence", g)
     def clear(self, g, t): self._rec("clear", g)
     def subtractGradient(self, g, p, vel): self._rec("subtractGradient", g)
@@ -168,10 +169,11 @@ def test_overlap_plan_hides_both_rounds():
     assert f[6] == "join dye"
     assert f[7] == "advect_fade %d %d 3" % (r0, r0 + 7) and f[8] == "advect_fade %d %d 3" % (r1 - 7, r1)
     assert f[9] == "exchange_async dye:7"                       # frame 2 begins: dye halo under the chain
-    assert f[10].startswith("vorticity %d %d" % (r0 - 82, r1 + 82))
+    assert f[10].startswith("vorticity %d %d" % (r0 - 82, r1 + 82))   # (a 2048-row slab plane is 128 MiB: two passes)
     # one GPU, 16384^2: a plane (1 GiB) outgrows the Infinity Cache -> both advections in one pass
     one = NS.plan_dump(W, H, 1, 0, None, params, [0])
     assert "advect_both 0 16384 5\n" in one and "advect_fade" not in one
+    assert "vorticity_apply 0 16384 0\n" in one and "applyVorticity" not in one
     assert not any(x.startswith("exchange ") for x in f)
 
 
