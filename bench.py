@@ -97,6 +97,26 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=25):
     return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
 
 
+def diffuse_microbench(s, W, H, sweeps=40, reps=10):
+    """The same for `diffuse` on the velocity: 40 sweeps of both planes as update() runs them
+    (Solver:506-517), velocity ~ U(-1,1).  Returns (ms per launch, sweeps per launch, ms per sweep)."""
+    from fluidsolver_amd import lib as L
+    lib = L.load()
+    vel = np.empty((2, H, W), np.float32)
+    lib.fs_harness_fill_uniform(vel.ctypes.data_as(C.c_void_p), vel.size, -1.0, 1.0, 4321)
+    s.write_field(L.FIELD_VELOCITY, vel)
+    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE)
+    s.stage(L.STAGE_DIFFUSE_VELOCITY, sweeps)   # warm-up
+    s.sync()
+    ms = C.c_float()
+    L.check(lib.fs_timer_begin(s.ctx), s.ctx)
+    for _ in range(reps):
+        L.check(lib.fs_stage(s.ctx, L.STAGE_DIFFUSE_VELOCITY, sweeps), s.ctx)
+    L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
+    launches = reps * ((sweeps + depth - 1) // depth)
+    return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
+
+
 def cpu_baseline(W, H, params, budget_s=20.0, omp=False):
     """The scalar oracle ("port", 1 thread; omp=True: the same code with OpenMP over rows on the box's CPU share,
     bit-identical) on a bounded sample of the same workload: whole frames of the same scripted input, as many as
@@ -377,6 +397,11 @@ def main():
         out["jacobi"] = {"gcell_updates_per_s_per_sweep": total_cells / (ms_sweep * 1e-3) / 1e9,
                          "us_per_sweep": ms_sweep * 1e3, "us_per_launch": ms_launch * 1e3,
                          "sweeps_per_launch": sweeps_per_launch}
+        dl, dspl, dsw = diffuse_microbench(s, W, H)
+        out["jacobi_diffuse_velocity"] = {"gcell_updates_per_s_per_sweep": total_cells / (dsw * 1e-3) / 1e9,
+                                          "us_per_sweep": dsw * 1e3, "us_per_launch": dl * 1e3, "sweeps_per_launch": dspl,
+                                          "effective_GBps": 16.0 * total_cells / (dsw * 1e-3) / 1e9,
+                                          "note": "both velocity planes per sweep, 16 algorithmic B/cell/sweep"}
         out["roofline"] = {"kernel": "k_jacobi_block<pressure> (%g sweeps/launch)" % sweeps_per_launch,
                            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),

@@ -154,44 +154,40 @@ __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
 {
     const int wup = wave > 0 ? wave - 1 : 0;            // tile rim rows have no neighbour: any value, never used
     const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
-    if (OP == OP_PRESSURE) {
-        // p, q and the divergence tile do not fit 64 VGPRs: one tile, rows rotated in place
-        for (int s = 0; s < T; ++s) {
-            const int buf = s & 1;
-            xch[buf][wave][0][lane] = f4_of(p[0]);
-            xch[buf][wave][1][lane] = f4_of(p[R - 1]);
-            __syncthreads();
-            Row prev = row_of(xch[buf][wup][1][lane]);
-            const Row below = row_of(xch[buf][wdn][0][lane]);
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const Row c = p[i];
-                const Row nx = (i < R - 1) ? p[i + 1] : below;
-                Row n = sweep_row<OP>(c, prev, nx, d[i], a, rden);
-                if (EDGE) {
-                    const Row fixedv = Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}};   // pressureOut = 0, Shaders:201-204
-                    if (fx0) n.a.x = fixedv.a.x;
-                    if (fx1) n.a.y = fixedv.a.y;
-                    if (fx2) n.b.x = fixedv.b.x;
-                    if (fx3) n.b.y = fixedv.b.y;
-                    if ((rowfixed >> i) & 1u) n = fixedv;
-                }
-                p[i] = n;
-                prev = c;
-            }
-        }
-        return;
-    }
-    Row q[R];
     int s = 0;
-    for (; s + 1 < T; s += 2) {
-        sweep_once<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
-        sweep_once<OP, R, NW, EDGE>(q, p, d, xch, 1, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+    if (OP == OP_DIFFUSE) {
+        Row q[R];
+        for (; s + 1 < T; s += 2) {
+            sweep_once<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+            sweep_once<OP, R, NW, EDGE>(q, p, d, xch, 1, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+        }
     }
-    if (s < T) {
-        sweep_once<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
+    // Pressure (p, q and the divergence tile do not fit 64 VGPRs) and the odd last sweep of a diffuse launch
+    // (a third live tile for one sweep made the compiler spill): one tile, rows rotated in place.
+    for (; s < T; ++s) {
+        const int buf = s & 1;
+        xch[buf][wave][0][lane] = f4_of(p[0]);
+        xch[buf][wave][1][lane] = f4_of(p[R - 1]);
+        __syncthreads();
+        Row prev = row_of(xch[buf][wup][1][lane]);
+        const Row below = row_of(xch[buf][wdn][0][lane]);
 #pragma unroll
-        for (int i = 0; i < R; ++i) p[i] = q[i];
+        for (int i = 0; i < R; ++i) {
+            const Row c = p[i];
+            const Row nx = (i < R - 1) ? p[i + 1] : below;
+            Row n = sweep_row<OP>(c, prev, nx, d[i], a, rden);
+            if (EDGE) {
+                // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
+                const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
+                if (fx0) n.a.x = fixedv.a.x;
+                if (fx1) n.a.y = fixedv.a.y;
+                if (fx2) n.b.x = fixedv.b.x;
+                if (fx3) n.b.y = fixedv.b.y;
+                if ((rowfixed >> i) & 1u) n = fixedv;
+            }
+            p[i] = n;
+            prev = c;
+        }
     }
 }
 
