@@ -104,12 +104,13 @@ def test_every_fusion_option_equals_the_unfused_frame(oracle, fuse):
     assert np.array_equal(s.read_field(L.FIELD_PRESSURE), o.field(PRESSURE))
 
 
-def test_out_of_cache_plan_equals_the_unfused_frame():
-    """8192^2: a plane (256 MiB) is as big as the Infinity Cache, so fs_step advects velocity and dye in one pass and
-    keeps the projection in separate passes -- the opposite choices of the 3072^2 frame.  No oracle at this size:
-    the fused frame must equal the unfused one bit for bit."""
+def test_out_of_cache_plan_equals_the_unfused_frame_and_the_oracle(oracle_omp):
+    """8192^2: a plane (256 MiB) is as big as the Infinity Cache, so fs_step advects velocity and dye in one pass,
+    computes curl + confinement in one pass and keeps the projection in separate passes -- the opposite choices of
+    the 3072^2 frame.  The fused frame must equal the unfused one and the (OpenMP) oracle bit for bit."""
     from fluidsolver_amd import lib as L
     from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, VELOCITY, Params
     W = H = 8192
     params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 12)
     out = []
@@ -125,6 +126,14 @@ def test_out_of_cache_plan_equals_the_unfused_frame():
         s.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.abs(out[0][0]).max() > 1.0
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(3):
+        for ptr in range(4):
+            pos, force, col = splat(W, H, 9 * f + 1, ptr, 4)
+            o.add_force(pos, force, col, 5.0, 0.5)
+        o.update(p)
+    assert np.array_equal(out[1][0], o.field(VELOCITY)) and np.array_equal(out[1][1], o.field(DENSITY))
 
 
 @pytest.mark.parametrize("W,H", [(1, 1), (2, 2), (3, 2), (1, 40), (40, 1), (4, 3), (257, 2), (2, 257), (65, 65)])
@@ -384,6 +393,57 @@ def test_full_size_3072_frame_matches_oracle(oracle_omp):
     for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
         assert np.array_equal(s.read_field(fg), o.field(fo))
     s.sync()
+
+
+def test_config2_fifty_frames_match_oracle(oracle_omp):
+    """BASELINE config 2 as bench.py runs it (3072^2, N = 40, one scripted splat per frame, hipGraph replay once
+    the parameters have settled), 50 frames: velocity, dye and pressure bit-identical to the oracle at the end and
+    at two checkpoints on the way (the jets are well developed by then: the advection gathers across rows)."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 3072
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(50):
+        pos, force, col = splat(W, H, f)
+        s.applyForce(pos, force, col)
+        o.add_force(pos, force, col, 5.0, 0.5)
+        s.update()
+        o.update(p)
+        if f in (9, 29, 49):
+            for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+                assert np.array_equal(s.read_field(fg), o.field(fo)), (f, fg)
+    assert float(np.abs(o.field(VELOCITY)).max()) > 10.0      # a real flow, not a resting fluid
+    s.sync()
+
+
+def test_config4_grid_frames_match_oracle(oracle_omp):
+    """The largest configured grid (BASELINE config 4: 16384^2, N = 40, eight scripted pointers) on one GPU, two
+    frames: every plane is 1 GiB, nothing fits the Infinity Cache, the frame runs the out-of-cache plan.  Velocity and
+    dye bit-identical to the (OpenMP) oracle."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, VELOCITY, Params
+    W = H = 16384
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in (1, 2):
+        for ptr in range(8):
+            pos, force, col = splat(W, H, 5 * f, ptr, 8)
+            s.applyForce(pos, force, col)
+            o.add_force(pos, force, col, 5.0, 0.5)
+        s.update()
+        o.update(p)
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY)):
+        got = s.read_field(fg)
+        assert np.array_equal(got, o.field(fo)), fg
+        del got
+    s.close()
 
 
 def test_full_size_properties():
