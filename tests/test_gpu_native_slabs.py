@@ -76,6 +76,74 @@ def test_local_group_equals_oracle(oracle_omp, world, name, mode):
         assert all(s["redo"] == 0 for s in stats)
 
 
+def test_config4_eight_slabs_equal_single_gpu_context():
+    """BASELINE config 4 at full size: the 16384^2 grid as EIGHT slabs of 2048 rows (the driver's 8-GPU strong-scaling
+    case, here as an in-process group with asynchronous copies and the overlapped plan) against fs_step on the whole
+    grid, N = 40, eight scripted pointers, 4 frames: bit-identical velocity and dye, halos of tens to hundreds of rows."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W = H = 16384
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    g = LocalGroup(W, H, params, 8, device=0, asynchronous=True, overlap=True)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        halos = []
+        for f in range(4):
+            for ptr in range(8):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, 8)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+            halos.append(g.slabs[0].last_halo)
+        g.sync()
+        s.sync()
+        assert max(halos) > 30, halos
+        for name, fid in (("vel", L.FIELD_VELOCITY), ("dye", L.FIELD_DENSITY)):
+            a = g.field(name)
+            assert np.array_equal(a, s.read_field(fid)), name
+            assert np.abs(a).max() > 0
+            del a
+    finally:
+        g.close()
+        s.close()
+
+
+def test_config5_slabs_equal_single_gpu_context():
+    """BASELINE config 5 at full slab size: 8192 x 8192 per slab, N = 100 (a 203-row stencil chain per frame), here
+    two slabs stacked to 8192 x 16384 against fs_step on the whole grid, 3 frames."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H = 8192, 16384
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 100)
+    g = LocalGroup(W, H, params, 2, device=0, asynchronous=True, overlap=True)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        for f in range(3):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, 2)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+        g.sync()
+        s.sync()
+        for name, fid in (("vel", L.FIELD_VELOCITY), ("dye", L.FIELD_DENSITY), ("p", L.FIELD_PRESSURE)):
+            a = g.field(name)
+            assert np.array_equal(a, s.read_field(fid)), name
+            assert np.abs(a).max() > 0
+            del a
+    finally:
+        g.close()
+        s.close()
+
+
 @pytest.mark.parametrize("mode", sorted(MODES))
 def test_local_group_equals_single_gpu_context_at_size(mode):
     """4 slabs of a 1536 x 1024 grid, N = 40, full-strength scripted splats (advection halo of tens of
