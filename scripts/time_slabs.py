@@ -28,7 +28,7 @@ def timed(step, sync, warm, frames):
 def main():
     W, rows_per_slab = int(sys.argv[1]), int(sys.argv[2])
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-    for K in (2, 4):
+    for K in ([int(k) for k in sys.argv[4].split(',')] if len(sys.argv) > 4 else (2, 4)):
         H = rows_per_slab * K
         s = FluidSolver(W, H)
         (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = PARAMS
