@@ -444,4 +444,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:   # a failed run still says so on the one JSON line (no number is made up)
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "Gcell-updates/s, full stable-fluids step", "value": None,
+                              "unit": "Gcell-updates/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                              "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
+        sys.exit(1)
