@@ -207,6 +207,12 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         e = hipHostMalloc((void **)&c->cfl_host, (size_t)world * sizeof(float), hipHostMallocDefault);
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipHostMalloc(cfl)");
     }
+    if (!rc) {
+        e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fs::hip_fail(e, "second stream / events");
+    }
     if (!rc && world > 1) {
         // exchange stream and its events (slab.hip)
         // (a high-priority stream was tried for it: with hipStreamCreateWithPriority the cross-stream event waits of
@@ -278,6 +284,7 @@ int fs_destroy(fs_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     drop_graphs(c);
     if (c->comm && c->comm->kind != 1 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
         c->comm->members[c->rank] = nullptr;
@@ -292,6 +299,9 @@ int fs_destroy(fs_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto *list : {&c->probes_live, &c->probes_free})
         for (const fs_ctx::WaitProbe &pr : *list) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->ev_cfl) (void)hipEventDestroy(c->ev_cfl);
     for (int i = 0; i < SLOT_COUNT; ++i) {
@@ -356,6 +366,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 4) ? value : 1; break;
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
+    case FS_OPT_SPLIT_PLANES: c->split_planes = value ? 1 : 0; break;
     case FS_OPT_TILE_VARIANT:
         if (fs::config_set_tile_variant(-1, value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
         break;

@@ -109,6 +109,10 @@ struct fs_ctx {
     int stable_frames = 0;              // frames since the parameters / options last changed (graphs are recorded once they settle)
     int with_particles = 0;
     int fuse = 1;
+    // independent planes of a diffuse loop as two concurrent chains (second stream, fork/join by event)
+    int split_planes = 1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool p_zero = false;                // planner state: pressure iterate is implicitly 0
     std::vector<fs::Step> steps;
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;

@@ -194,9 +194,23 @@ struct Planner {
                 const float dt = c->params.deltaTime;
                 const int np = F.np;
                 const size_t plane = c->plane;
+                // The planes of a diffuse loop do not depend on each other.  As ONE launch per chunk of sweeps, every
+                // launch ends in a partly filled last round of workgroups (3072^2: 1664 workgroups on 512 slots) before
+                // the next may start; as two chains on two streams (fork / join by event, captured into the frame's
+                // graph as parallel branches) the tail of one chain is filled by the other.  Same kernels, same bits.
+                const bool split = c->split_planes && np > 1 && c->stream2;
+                hipStream_t st2 = c->stream2;
+                hipEvent_t ef = c->ev_fork, ej = c->ev_join;
                 compute("diffuse_n", g, n, [=]() {                                    // Solver:506-517, :563-573
                     int ib = 0;
-                    return fs_k_diffuse_n(&g, src, dst, np, plane, coeff, dt, n, &ib, st);
+                    if (!split) return fs_k_diffuse_n(&g, src, dst, np, plane, coeff, dt, n, &ib, st);
+                    FS_HIP(hipEventRecord(ef, st));
+                    FS_HIP(hipStreamWaitEvent(st2, ef, 0));
+                    const int rc1 = fs_k_diffuse_n(&g, src, dst, 1, plane, coeff, dt, n, &ib, st);
+                    const int rc2 = fs_k_diffuse_n(&g, src + plane, dst + plane, np - 1, plane, coeff, dt, n, &ib, st2);
+                    FS_HIP(hipEventRecord(ej, st2));           // joined even after an error: a capture must end whole
+                    FS_HIP(hipStreamWaitEvent(st, ej, 0));
+                    return rc1 ? rc1 : rc2;
                 });
             }
             if (jacobi_launch_count(pressure ? 0 : 1, n) & 1) F.cur ^= 1;

@@ -395,6 +395,34 @@ def test_full_size_3072_frame_matches_oracle(oracle_omp):
     s.sync()
 
 
+@pytest.mark.parametrize("W,H", [(600, 500), (3072, 1024)])
+def test_diffuse_planes_as_two_chains_equal_one_chain(oracle_omp, W, H):
+    """FS_OPT_SPLIT_PLANES: the velocity planes (1 + 1) and the dye planes (1 + 2) of the diffuse loops as two
+    concurrent launch chains, eager frames and graph replays: same bits as one chain and as the oracle."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, VELOCITY, Params
+    params = (1.5e-4, 0.00002, 0.5, 10.0, 0.002, 21)      # odd number of launches per loop, dye diffusion on
+    out = []
+    for mode in (0, 1):
+        s = make_solver(W, H, params)
+        s.set_option(L.OPT_SPLIT_PLANES, mode)
+        for f in range(7):
+            pos, force, col = splat(W, H, 3 * f + 1)
+            s.applyForce(pos, force, col)
+            s.update()
+        out.append((s.read_field(L.FIELD_VELOCITY), s.read_field(L.FIELD_DENSITY)))
+        s.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(7):
+        pos, force, col = splat(W, H, 3 * f + 1)
+        o.add_force(pos, force, col, 5.0, 0.5)
+        o.update(p)
+    assert np.array_equal(out[1][0], o.field(VELOCITY)) and np.array_equal(out[1][1], o.field(DENSITY))
+
+
 def test_config2_fifty_frames_match_oracle(oracle_omp):
     """BASELINE config 2 as bench.py runs it (3072^2, N = 40, one scripted splat per frame, hipGraph replay once
     the parameters have settled), 50 frames: velocity, dye and pressure bit-identical to the oracle at the end and
