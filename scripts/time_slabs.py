@@ -45,6 +45,10 @@ def main():
         for name, (asy, ovl) in (("blocking plain", (False, False)), ("async plain", (True, False)),
                                  ("blocking overlap", (False, True)), ("async overlap", (True, True))):
             g = LocalGroup(W, H, PARAMS, K, device=0, asynchronous=asy, overlap=ovl)
+            if os.environ.get("FS_SPLIT") is not None:
+                from fluidsolver_amd import lib as L
+                for sl in g.slabs:
+                    L.check(sl.lib.fs_set_option(sl.ctx, L.OPT_SPLIT_PLANES, int(os.environ["FS_SPLIT"])), sl.ctx)
 
             def stepk(f):
                 for ptr in range(K):
