@@ -211,6 +211,9 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming);
         if (e != hipSuccess) rc = fs::hip_fail(e, "second stream / events");
     }
     if (!rc && world > 1) {
@@ -285,6 +288,7 @@ int fs_destroy(fs_ctx *c)
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     drop_graphs(c);
     if (c->comm && c->comm->kind != 1 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
         c->comm->members[c->rank] = nullptr;
@@ -301,6 +305,9 @@ int fs_destroy(fs_ctx *c)
         for (const fs_ctx::WaitProbe &pr : *list) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork3) (void)hipEventDestroy(c->ev_fork3);
+    if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->ev_cfl) (void)hipEventDestroy(c->ev_cfl);

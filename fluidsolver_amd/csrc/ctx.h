@@ -40,6 +40,7 @@ enum { SLOT_VEL = 0, SLOT_DYE = 1, SLOT_SYNC = 2, SLOT_COUNT = 3 };
 struct Step {
     int kind = STEP_COMPUTE;
     const char *what = "";
+    bool hidden = false;                // stream plumbing (fork / join of a side chain): not part of the plan dump
     int yb = 0, ye = 0, n = 0;          // rows computed / sweeps (plan dumps, tests)
     std::function<int()> run;           // STEP_COMPUTE: enqueue the kernel(s) on the context's stream
     std::vector<Xfer> xf;               // STEP_EXCHANGE
@@ -113,6 +114,9 @@ struct fs_ctx {
     int split_planes = 1;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the dye diffusion loop of a single-GPU frame runs beside the whole velocity chain on a third stream
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
     bool p_zero = false;                // planner state: pressure iterate is implicitly 0
     std::vector<fs::Step> steps;
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;

@@ -69,7 +69,25 @@ struct Planner {
     fs_ctx *c;
     const bool multi;
     const int G;
+    hipStream_t lane = nullptr;   // != null: the Jacobi loops planned now run as a side chain on this stream
     explicit Planner(fs_ctx *ctx) : c(ctx), multi(ctx->world > 1), G(ctx->G) {}
+
+    // One GPU, dye diffusion on (Solver:562-574): that loop touches nothing but the dye, so it runs beside the whole
+    // velocity chain (third stream, forked at the start of the frame, joined where update() has it) and fills the
+    // idle issue slots of the pressure loop and the streaming passes.
+    bool dye_diffusion_hoisted() const
+    {
+        return !multi && c->split_planes && c->params.diffusion > 0.0f && c->params.solverIterations > 0;
+    }
+    void plumbing(const char *what, std::function<int()> fn)
+    {
+        Step s;
+        s.kind = STEP_COMPUTE;
+        s.what = what;
+        s.hidden = true;
+        s.run = std::move(fn);
+        c->steps.push_back(std::move(s));
+    }
 
     int eff(int f) const { return std::min(c->f[f].valid, G); }   // usable depth: valid AND present in the buffer
 
@@ -171,7 +189,7 @@ struct Planner {
             }
             const fs_grid g = grid_of(c, out_depth);
             float *src = F.p(), *dst = F.t();
-            hipStream_t st = c->stream;
+            hipStream_t st = lane ? lane : c->stream;
             if (pressure) {
                 const int pz = c->p_zero ? 1 : 0;
                 c->p_zero = false;
@@ -198,7 +216,7 @@ struct Planner {
                 // launch ends in a partly filled last round of workgroups (3072^2: 1664 workgroups on 512 slots) before
                 // the next may start; as two chains on two streams (fork / join by event, captured into the frame's
                 // graph as parallel branches) the tail of one chain is filled by the other.  Same kernels, same bits.
-                const bool split = c->split_planes && np > 1 && c->stream2;
+                const bool split = c->split_planes && np > 1 && c->stream2 && !lane;
                 hipStream_t st2 = c->stream2;
                 hipEvent_t ef = c->ev_fork, ej = c->ev_join;
                 compute("diffuse_n", g, n, [=]() {                                    // Solver:506-517, :563-573
@@ -273,6 +291,15 @@ struct Planner {
         Field &V = c->f[F_VEL];
 
         if (multi && h_spec >= 0) ensure({{F_DYE, h_spec}}, SLOT_DYE, true);
+        if (dye_diffusion_hoisted()) {                                                // :562-574, early and aside
+            hipStream_t s3 = c->stream3;
+            hipEvent_t ef = c->ev_fork3, ej = c->ev_join3;
+            plumbing("fork dye", [=]() { FS_HIP(hipEventRecord(ef, st)); FS_HIP(hipStreamWaitEvent(s3, ef, 0)); return (int)FS_OK; });
+            lane = s3;
+            sweeps(false, F_DYE, N, 0);
+            lane = nullptr;
+            plumbing("dye chain end", [=]() { FS_HIP(hipEventRecord(ej, s3)); return (int)FS_OK; });
+        }
         if (vort_on) {                                                                // :486-502
             need(F_VEL, need_v0);
             const int dw = multi ? std::min(need_v1 + 1, eff(F_VEL) - 1) : 0;
@@ -424,7 +451,10 @@ struct Planner {
                 c->f[F_DYE].cur ^= 1;
             } else {
                 advect(F_VEL, false, adv);                                            // :550-558
-                if (ddn) {                                                            // :562-574
+                if (ddn && dye_diffusion_hoisted()) {                                 // planned by plan_a: wait for it here
+                    hipEvent_t ej = c->ev_join3;
+                    plumbing("join dye", [=]() { FS_HIP(hipStreamWaitEvent(st, ej, 0)); return (int)FS_OK; });
+                } else if (ddn) {                                                     // :562-574
                     sweeps(false, F_DYE, N, h);
                     need(F_DYE, h);
                 }
@@ -958,6 +988,7 @@ static void append_plan(const fs_ctx *c, std::string &out)
     static const char *names[F_COUNT] = {"vel", "dye", "p", "div", "vort"};
     char line[160];
     for (const Step &s : c->steps) {
+        if (s.hidden) continue;
         if (s.kind == STEP_COMPUTE) {
             snprintf(line, sizeof(line), "%s %d %d %d\n", s.what, s.yb, s.ye, s.n);
             out += line;

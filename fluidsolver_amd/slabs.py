@@ -365,6 +365,11 @@ class SlabSolver:
         if h_spec is not None:
             self._ensure([("dye", h_spec)], "exchange_async")                  # under the whole stencil chain
 
+        hoisted = ddn and not multi
+        if hoisted:
+            # one GPU: the dye diffusion touches nothing but the dye, the native runtime runs it beside the whole
+            # velocity chain (a third stream); here it simply comes first                     :562-574
+            self._sweeps("diffuse", "dye", N, 0)
         if vort_on:                                                            # :486-502
             self._need("vel", need_v0)
             dw = min(need_v1 + 1, eff("vel") - 1) if multi else 0
@@ -479,7 +484,7 @@ class SlabSolver:
                 self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]
                 if multi:
                     V["vel"] = adv
-                if ddn:
+                if ddn and not hoisted:
                     self._sweeps("diffuse", "dye", N, h)                       # :562-574
                     self._need("dye", h)
                 self._advect_rows("dye", self.f["vel"], self.r0, self.r1, fused)   # :577-584 (+ :587-591 when fused)

@@ -272,7 +272,8 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */
        FS_OPT_SPLIT_PLANES = 12,  /* 1 (default): the independent planes of a diffuse loop run as two concurrent chains of
                                      launches (a second stream, fork/join by event; parallel branches of the frame's graph),
-                                     so the partly filled last round of one launch is filled by the other chain; 0 = one chain */
+                                     so the partly filled last round of one launch is filled by the other chain, and the dye diffusion loop
+                                     of a single-GPU frame runs beside the velocity chain (third stream); 0 = one chain */
        FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
        FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* fs_config_set/get only: tile shape of the diffuse loops alone */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic

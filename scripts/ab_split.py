@@ -9,7 +9,7 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 H = int(sys.argv[2]) if len(sys.argv) > 2 else W
 lib = L.load()
 s = FluidSolver(W, H); s.displayMode = None
-(s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+(s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = (1.5e-4, float(os.environ.get("DIFFUSION", "0")), 0.5, 10.0, 0.002, 40)
 f = 0
 for _ in range(30):
     pos, force, col = splat(W, H, f); s.applyForce(pos, force, col); s.update(); f += 1
@@ -28,7 +28,7 @@ for rep in range(3):
 out = []
 for mode in (0, 1):
     t = FluidSolver(W, H); t.displayMode = None
-    (t.viscosity, t.diffusion, t.deltaTime, t.vorticityStrength, t.fadeSpeed, t.solverIterations) = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    (t.viscosity, t.diffusion, t.deltaTime, t.vorticityStrength, t.fadeSpeed, t.solverIterations) = (1.5e-4, float(os.environ.get("DIFFUSION", "0")), 0.5, 10.0, 0.002, 40)
     t.set_option(L.OPT_SPLIT_PLANES, mode)
     for f in range(8):
         pos, force, col = splat(W, H, f); t.applyForce(pos, force, col); t.update()

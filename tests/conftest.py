@@ -23,3 +23,14 @@ def oracle():
 def oracle_omp():
     from oracle_binding import Oracle
     return Oracle(omp=True)
+
+
+def pytest_collection_finish(session):
+    """GPU runs: bring torch's HIP context up BEFORE the library's first HIP call.  On this image torch cannot
+    find the device once another HIP user in the process has initialised it first ("no ROCm-capable device"), so
+    without this the tests that use torch tensors pass or fail with the order the files are run in."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
