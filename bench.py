@@ -18,6 +18,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -41,6 +42,43 @@ WORKLOADS = {
     "config5": dict(W=8192, H=8192, params=(1.5e-4, 0.0, 0.5, 10.0, 0.002, 100), particles=0, scaling="weak",
                     desc="8192x8192 per GPU, 100 pressure iters, weak scaling"),
 }
+
+
+# Watchdog: a multi-rank run that stops making progress (a halo exchange that never completes, a rank that died)
+# must still end with ONE JSON line that says where it stopped, not with a silent hang.  The main thread names the
+# phase it is in; if the whole run outlives FS_BENCH_WATCHDOG_S seconds (default 900; 0 = off) every rank leaves
+# through os._exit and rank 0 prints what it has: the finished main line if only the untimed extra hung, else an
+# error line (no number is made up).
+STATE = {"phase": "start", "out": None}
+
+
+def phase(name):
+    STATE["phase"] = name
+
+
+def start_watchdog():
+    limit = float(os.environ.get("FS_BENCH_WATCHDOG_S", "900"))
+    if limit <= 0:
+        return
+
+    def bark():
+        time.sleep(limit)
+        rank0 = int(os.environ.get("RANK", "0")) == 0
+        msg = "watchdog: no result after %.0f s, stopped in phase '%s'" % (limit, STATE["phase"])
+        sys.stderr.write("[bench rank %s] %s\n" % (os.environ.get("RANK", "0"), msg))
+        sys.stderr.flush()
+        if rank0:
+            out = STATE["out"]
+            if out is not None:
+                out = dict(out, config4_strong={"error": msg})
+            else:
+                out = {"metric": "Gcell-updates/s, full stable-fluids step", "value": None, "unit": "Gcell-updates/s",
+                       "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": msg}
+            print(json.dumps(out), flush=True)
+        else:
+            time.sleep(5.0)   # the launcher ends every rank as soon as one has left: rank 0 prints first
+        os._exit(3)
+    threading.Thread(target=bark, daemon=True).start()
 
 
 def make_single(W, H, params, particles):
@@ -269,6 +307,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="Jacobi temporal-blocking depth (0 = library default)")
     args = ap.parse_args()
 
+    start_watchdog()
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -312,14 +351,18 @@ def main():
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        phase("gloo rendezvous")
         try:
             dist.init_process_group("gloo")
         finally:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
         H = Hg * world if wl["scaling"] == "weak" else Hg
+        phase("RCCL communicator + slab context")
         s = RcclSlab(W, H, params, device=local_rank, rank=rank, world=world, dist=dist)
+        phase("RCCL self-test (grouped send/recv + all-reduce)")
         L.check(lib.fs_comm_selftest(s.comm, 1 << 16))
+        phase("slab self-check (small grid as N slabs against 1 GPU)")
         slab_check = slab_selfcheck(dist, rank, world, local_rank)
         n_ptr = wl.get("pointers", world)   # weak scaling: one pointer per slab; config 4: always eight
         step = lambda f: s.frame(f, n_pointers=n_ptr)   # noqa: E731
@@ -333,6 +376,7 @@ def main():
         forced = os.environ.get("FS_BENCH_SLAB_OVERLAP")
         ab, f0 = {}, 0
         for mode in ((0, 1) if forced is None else (int(forced),)):   # plain first: the halo history is warm for the guess
+            phase("untimed A/B of the slab plans, %s" % ("overlapped" if mode else "plain"))
             s.set_overlap(mode)
             for f in range(f0, f0 + 4):
                 step(f)
@@ -349,6 +393,7 @@ def main():
         s.set_overlap(overlap)
 
     f0 = f0 if slabs else 0
+    phase("warm-up + timed frames")
     for f in range(f0, f0 + args.warmup):
         step(f)
     sync_all()
@@ -387,6 +432,7 @@ def main():
         "frames_per_s": fps,
     }
 
+    phase("micro-benchmarks / CPU baseline / exposed waits")
     if not slabs:
         alg = ALG_BYTES_FRAME_CONFIG2 if params[5] == 40 else None
         if alg:
@@ -432,6 +478,8 @@ def main():
                        "overlap": bool(overlap), "advection_replans": st["redo"],
                        "untimed_ab_ms_per_frame": {"overlap": ab.get(1), "plain": ab.get(0)}}
     if args.workload == "config2" and os.environ.get("FS_BENCH_NO_CONFIG4") != "1":
+        STATE["out"] = out
+        phase("config4_strong extra (16384^2)")
         try:
             s.close()
             out["config4_strong"] = config4_extra(world if slabs else 1, rank, local_rank, dist if slabs else None)
