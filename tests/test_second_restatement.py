@@ -1,0 +1,116 @@
+"""The scalar C oracle against a second, independently written restatement of the same shaders (tests/shader_numpy.py:
+whole-array numpy): every kernel on random fields and whole scripted runs must agree BIT FOR BIT.  The reference has
+no golden vectors (parity unpinned); this is the N-version check that stands in for them."""
+import numpy as np
+import pytest
+
+import shader_numpy as S
+from oracle_binding import DENSITY, DIVERGENCE, PRESSURE, VELOCITY, VORTICITY, Oracle, Params, full_grid
+
+SIZES = [(37, 29), (64, 64), (130, 67), (3, 3), (5, 3), (2, 7), (1, 1)]
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def rnd(rng, H, W, scale=1.0):
+    return (rng.standard_normal((H, W)) * scale).astype(np.float32)
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_kernels_agree_bit_for_bit(oracle, W, H):
+    rng = np.random.default_rng(W * 1000 + H)
+    g = full_grid(W, H)
+    u, v, w, p, d = (rnd(rng, H, W, s) for s in (3.0, 3.0, 2.0, 1.0, 1.0))
+    dye = [np.abs(rnd(rng, H, W, 50.0)) - 5.0 for _ in range(3)]   # some negatives: fade clamps them
+
+    out = np.full((H, W), np.nan, np.float32)
+    oracle.divergence(g, u, v, out)
+    assert same(out, S.divergence(u, v))
+    oracle.calculateVorticity(g, u, v, out)
+    assert same(out, S.calculateVorticity(u, v))
+    oracle.pressureSolve(g, d, p, out)
+    assert same(out, S.pressureSolve(d, p))
+    for visc in (1.5e-4, 1e-5, 0.01):
+        oracle.diffuse(g, u, out, visc, 0.5)
+        assert same(out, S.diffuse(u, visc, 0.5))
+
+    uu, vv = u.copy(), v.copy()
+    oracle.subtractGradient(g, p, uu, vv)
+    eu, ev = S.subtractGradient(p, u, v)
+    assert same(uu, eu) and same(vv, ev)
+
+    uu, vv = u.copy(), v.copy()
+    oracle.applyVorticity(g, w, uu, vv, 10.0, 0.5)
+    eu, ev = S.applyVorticity(w, u, v, 10.0, 0.5)
+    assert same(uu, eu) and same(vv, ev)
+
+    for dt, s in ((0.5, 1.0), (0.5, 40.0), (1.0, 1000.0)):          # sub-cell, many cells, clamped at the walls
+        us, vs = (u * s).astype(np.float32), (v * s).astype(np.float32)
+        for src in (us, vs, dye[0]):
+            assert oracle.advect(g, us, vs, src, out, dt) == 0
+            assert same(out, S.advect(us, vs, [src], dt)[0])
+
+    dd = dye[1].copy()
+    oracle.fadeDensity(g, dd, 0.002)
+    assert same(dd, S.fadeDensity(dye[1], 0.002))
+
+    out4 = np.full((4, H, W), np.nan, np.float32)
+    oracle.renderDensity(g, dye[0], dye[1], dye[2], out4, 1.3)
+    assert same(out4, np.stack(S.renderDensity(dye, 1.3)))
+    oracle.renderVelocity(g, u, v, out4, 0.05)
+    assert same(out4, np.stack(S.renderVelocity(u, v, 0.05)))
+    oracle.renderSpeed(g, u, v, out4, 0.05)
+    assert same(out4, np.stack(S.renderSpeed(u, v, 0.05)))
+
+
+@pytest.mark.parametrize("pos,radius", [((20.3, 11.7), 5.0), ((0.0, 0.0), 9.5), ((36.0, 28.0), 50.0), ((18.0, 14.0), 0.4)])
+def test_splat_agrees_bit_for_bit(oracle, pos, radius):
+    W, H = 37, 29
+    rng = np.random.default_rng(7)
+    g = full_grid(W, H)
+    vel = [rnd(rng, H, W) for _ in range(2)]
+    dens = [rnd(rng, H, W) for _ in range(3)]
+    a = [x.copy() for x in vel + dens]
+    oracle.addForces(g, *a, pos, (31.0, -17.5), (100.0, 40.0, 3.0), radius, 0.5)
+    S.addForces(vel, dens, pos, (31.0, -17.5), (100.0, 40.0, 3.0), radius, 0.5)
+    for x, y in zip(a, vel + dens):
+        assert same(x, y)
+
+
+@pytest.mark.parametrize("W,H,params,frames", [
+    (96, 80, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 20), 12),      # the defaults of config 1 + vorticity
+    (80, 96, (1.5e-4, 1e-5, 0.5, 10.0, 0.002, 7), 8),       # dye diffusion on, odd iteration count (swap parity)
+    (64, 64, (0.0, 0.0, 0.5, 0.0, 0.01, 5), 6),             # viscosity and vorticity off: both branches skipped
+])
+def test_scripted_frames_agree_bit_for_bit(oracle, W, H, params, frames):
+    """splat + update() for several frames: step order, loop counts, swaps and conditions (Solver:477-591)"""
+    import math
+    o = oracle.solver(W, H)
+    s = S.Solver(W, H)
+    p = Params(*params)
+    prev = None
+    for f in range(frames):
+        pos = (W * (0.5 + 0.35 * math.sin(2 * math.pi * 3 * f / 60.0)),
+               H * (0.5 + 0.35 * math.sin(2 * math.pi * 2 * f / 60.0 + math.pi / 2)))
+        force = (0.0, 0.0) if prev is None else ((pos[0] - prev[0]) * 24.0, (pos[1] - prev[1]) * 24.0)
+        prev = pos
+        col = (100.0 * (f % 3 == 0), 100.0 * (f % 3 == 1), 100.0 * (f % 3 == 2))
+        o.add_force(pos, force, col, 5.0, params[2])
+        s.add_force(pos, force, col, 5.0, params[2])
+        o.update(p)
+        s.update(*params)
+        assert same(o.field(VELOCITY), np.stack(s.vel)), f
+        assert same(o.field(DENSITY), np.stack(s.dens)), f
+        assert same(o.field(PRESSURE)[0], s.p), f
+        assert same(o.field(DIVERGENCE)[0], s.div), f
+        if params[3] > 0:
+            assert same(o.field(VORTICITY)[0], s.w), f
+    assert float(np.abs(np.stack(s.vel)).max()) > 0 and float(np.stack(s.dens).max()) > 0
