@@ -182,3 +182,32 @@ class Solver:
                 self.dens = [diffuse(c, diffusion, dt) for c in self.dens]
         self.dens = advect(self.vel[0], self.vel[1], self.dens, dt)      # :577-584
         self.dens = [fadeDensity(c, fadeSpeed) for c in self.dens]       # :587-591
+
+
+def particles_update(u, v, arrs, momentum, fluidForce, fluidDecayRate, linkToViscosity, viscosity, window):
+    """ParticleSystem.update(), fluidSolver/Models/ParticleSystem.swift:242-304, on SoA arrays (px, py, vx, vy, life,
+    mass, age), with the velocity lookup of FluidSolver.getVelocityAt (FluidSolver.swift:648-657) done for real on the
+    field -- the build's definitions where the reference is a stub: fluidVel = cell velocity /
+    (W, H); a dead tracer (life == 0) is skipped and stays in the arrays.  Returns the new arrays."""
+    px, py, vx, vy, life, mass, age = arrs
+    H, W = u.shape
+    ww, wh = F(window[0]), F(window[1])
+    nx, ny = px * (F(1.0) / ww), py * (F(1.0) / wh)                                        # :245-255
+    cx = np.maximum(F(0), np.minimum(F(W - 1), nx * F(W))).astype(np.int64)                # Solver:650
+    cy = np.maximum(F(0), np.minimum(F(H - 1), ny * F(H))).astype(np.int64)                # Solver:651
+    fvx, fvy = u[cy, cx] / F(W), v[cy, cx] / F(H)
+    ageDecay = np.maximum(F(0), F(1.0) - age * F(fluidDecayRate))                          # :259
+    eff = F(0.1) + (F(viscosity) / F(0.01)) * F(0.9) if linkToViscosity else F(fluidForce)  # :262-268
+    k = mass * eff * ageDecay                                                              # :271
+    fcx, fcy = fvx * k * ww, fvy * k * wh
+    em = F(momentum) + (F(1.0) - F(momentum)) * np.minimum(F(1.0), age * F(2.0))           # :272
+    nvx, nvy = fcx + vx * em, fcy + vy * em                                                # :273-275
+    npx, npy = px + nvx, py + nvy                                                          # :276
+    nage = age + F(1.0) / F(60.0)                                                          # :279
+    m = F(50)                                                                              # :282
+    off = (npx < -m) | (npx > ww + m) | (npy < -m) | (npy > wh + m)                        # :283-286
+    nl = np.where(off, F(0), life) * F(0.999)                                              # :287, :291
+    nl = np.where(nl < F(0.01), F(0), nl)                                                  # :294-295
+    alive = life != 0
+    return [np.where(alive, new, old).astype(F) for new, old in
+            zip((npx, npy, nvx, nvy, nl, mass, nage), (px, py, vx, vy, life, mass, age))]

@@ -114,3 +114,28 @@ def test_scripted_frames_agree_bit_for_bit(oracle, W, H, params, frames):
         if params[3] > 0:
             assert same(o.field(VORTICITY)[0], s.w), f
     assert float(np.abs(np.stack(s.vel)).max()) > 0 and float(np.stack(s.dens).max()) > 0
+
+
+@pytest.mark.parametrize("link", [0, 1])
+def test_tracer_update_agrees_bit_for_bit(oracle, link):
+    from oracle_binding import ParticleParams
+    W, H, n = 61, 47, 5000
+    rng = np.random.default_rng(11 + link)
+    g = full_grid(W, H)
+    u, v = rnd(rng, H, W, 30.0), rnd(rng, H, W, 30.0)
+    window = (800.0, 600.0)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)   # noqa: E731
+    arrs = [f32(rng.uniform(-60, 860, n)), f32(rng.uniform(-60, 660, n)),        # some start off screen
+            f32(rng.standard_normal(n) * 3), f32(rng.standard_normal(n) * 3),
+            f32(rng.uniform(0.0, 1.0, n)), f32(rng.uniform(0.1, 1.0, n)), f32(rng.uniform(0.0, 3.0, n))]
+    arrs[4][::7] = 0.0            # dead tracers are skipped
+    arrs[4][1::7] = 0.01005       # dies by the fade of this update
+    got = [a.copy() for a in arrs]
+    exp = arrs
+    pp = ParticleParams(0.9, 0.6, 0.5, link, 0.004, *window)
+    for _ in range(5):
+        oracle.particles_update(g, u, v, pp, got)
+        exp = S.particles_update(u, v, exp, 0.9, 0.6, 0.5, link, 0.004, window)
+        for a, b in zip(got, exp):
+            assert same(a, b)
+    assert (got[4] == 0).sum() > (arrs[4] == 0).sum()
