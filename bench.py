@@ -454,6 +454,19 @@ def main():
                            "note": "achieved = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
                                    "HIP-event launch time; temporal blocking keeps T sweeps on chip, so the "
                                    "effective figure may exceed the HBM peak"}
+        # Second bound, the one that binds while the planes sit in the Infinity Cache: VALU issue.
+        # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-slots/s; a pressure sweep issues 6.3 slots per cell of the
+        # 256 x 64 register tile, of which (256 - 2 HX)(64 - 2 T) cells are stored (HX = T rounded up to 4).
+        T = int(sweeps_per_launch)
+        hx = (T + 3) // 4 * 4
+        stored = (256 - 2 * hx) * (64 - 2 * T) / (256.0 * 64.0)
+        if stored > 0:
+            issue_peak = 256 * 4 * 16 * 2.4e9
+            t_issue = 6.3 * total_cells / stored / issue_peak
+            out["roofline"]["valu_issue"] = {"slots_per_cell": 6.3, "stored_fraction_of_tile": stored,
+                                             "peak_lane_slots_per_s": issue_peak, "us_per_sweep_at_peak": t_issue * 1e6,
+                                             "frac": t_issue / (ms_sweep * 1e-3),
+                                             "note": "informational: fraction of the VALU issue rate the sweep reaches"}
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
             out["cpu_baseline_all_cores"] = cpu_baseline(W, H, params, budget_s=8.0, omp=True)
