@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 namespace fs {
@@ -152,6 +153,31 @@ static int st_particles(fs_ctx *c)
                                  c->part[3], c->part[4], c->part[5], c->part[6], c->stream);
 }
 
+// ---- staging area of fs_particle_lines_static (the entry point that allocates nothing) ----------------------
+// A file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the
+// process ends (5 MiB).  In host code the array's NAME is only a stand-in for the symbol, never a device
+// address: the address on a device comes from hipGetSymbolAddress with that device current, once per device
+// (scratch_for_device, called by fs_create), and only that pointer is ever handed to kernels and copies.
+static __device__ __align__(256) float scratch[5 * FS_LINES_STATIC_MAX];
+constexpr int kMaxDevices = 64;
+static float *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+static int scratch_for_device(int device, float **out)   // `device` must be the current device
+{
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) { fs::set_error("device %d out of range", device); return FS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        float *ptr = nullptr;
+        FS_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) { fs::set_error("hipGetSymbolAddress(scratch) returned NULL on device %d", device); return FS_ERR_HIP; }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return FS_OK;
+}
+
 // Allocates one slab (world 1: the whole grid).  dry = plan-only context without device memory.
 int create_common(int width, int height, int device, fs_comm *comm, int world, int rank, int ghost_rows,
                   long max_particles, bool dry, fs_ctx **out)
@@ -233,6 +259,7 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(particles)");
     }
+    if (!rc) rc = scratch_for_device(device, &c->lines_scratch);
     if (rc) { fs_destroy(c); return rc; }
     rc = fs_reset(c);
     if (rc) { fs_destroy(c); return rc; }
@@ -663,6 +690,31 @@ int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particl
     (void)hipFree(xy);
     if (rc) return ctx_fail(c, rc);
     if (e != hipSuccess) return ctx_fail(c, fs::hip_fail(e, "fs_particle_lines"));
+    return FS_OK;
+}
+
+// fs_particle_lines without any allocation: the vertices are staged in the device's copy of `scratch`
+// (resolved by fs_create).  Every call on a GPU shares that one array: the kernel overwrites the 5 n floats it
+// uses, so nothing has to be cleared, but two calls that overlap on one GPU (two threads, two contexts) race.
+int fs_particle_lines_static(fs_ctx *c, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha)
+{
+    CTX(c);
+    const long n = c->n_particles;
+    if (n == 0) return FS_OK;
+    if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines_static: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
+    if (n > FS_LINES_STATIC_MAX) {
+        fs::set_error("fs_particle_lines_static: %ld tracers exceed the static staging area (FS_LINES_STATIC_MAX = %d); "
+                      "use fs_particle_lines", n, FS_LINES_STATIC_MAX);
+        return ctx_fail(c, FS_ERR_INVALID);
+    }
+    float *xy = c->lines_scratch;
+    if (!xy) { fs::set_error("fs_particle_lines_static: no staging area on device %d", c->device); return ctx_fail(c, FS_ERR_STATE); }
+    float *al = xy + 4 * n;
+    TRY(c, fs_k_particle_lines(n, c->part[0], c->part[1], c->part[2], c->part[3], c->part[4], viewportW, viewportH,
+                               particleScale, xy, al, c->stream));
+    TRYHIP(c, hipStreamSynchronize(c->stream));
+    TRYHIP(c, hipMemcpy(host_xy4, xy, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    TRYHIP(c, hipMemcpy(host_alpha, al, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return FS_OK;
 }
 

@@ -137,6 +137,7 @@ struct fs_ctx {
     float *tr_matrix_host = nullptr;    // pinned
     std::vector<long> tr_send_off, tr_recv_cnt;
     long stat_migrated = 0;
+    float *lines_scratch = nullptr;     // this device's copy of the static staging array (fs_particle_lines_static); not owned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
     char error[512] = "";
 };

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libfluidsolver_hip.so")
 
 FS_OK = 0
 COMM_ID_BYTES = 128
+LINES_STATIC_MAX = 262144
 ERRORS = {-1: "FS_ERR_INVALID", -2: "FS_ERR_HIP", -3: "FS_ERR_NOMEM", -4: "FS_ERR_HALO", -5: "FS_ERR_STATE"}
 
 FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE, FIELD_VORTICITY, FIELD_DISPLAY = range(6)
@@ -107,6 +108,7 @@ SIGNATURES = {
     "fs_particles_count": (_l, [_p]),
     "fs_particles_reserve": (_i, [_p, _l]),
     "fs_particle_lines": (_i, [_p, _f, _f, _f, _p, _p]),
+    "fs_particle_lines_static": (_i, [_p, _f, _f, _f, _p, _p]),
     "fs_k_particle_lines": (_i, [_l, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p]),
     "fs_set_particle_params": (_i, [_p, C.POINTER(ParticleParams)]),
     "fs_k_tracer_count": (_i, [_G, C.POINTER(ParticleParams), _i, _i, _l, _p, _p, _p, _p]),

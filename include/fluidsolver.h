@@ -334,6 +334,14 @@ long fs_particles_count(fs_ctx *ctx);
  * the only way to get tracer storage (capacity is per rank: leave headroom for tracers that migrate in). */
 /* Line vertices of the context's tracers (fs_k_particle_lines) into host arrays of 4 n and n floats. Blocking. */
 int fs_particle_lines(fs_ctx *ctx, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha);
+/* fs_particle_lines for callers that cannot allocate (code under HIP graph capture rules, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same outputs, bit for bit, but the
+ * vertices are staged in a file-scope device array of the library (5 x FS_LINES_STATIC_MAX floats = 5 MiB per GPU,
+ * resolved once per device by fs_create) instead of a per-call hipMalloc: no hipMalloc / hipFree is called.
+ * More than FS_LINES_STATIC_MAX tracers -> FS_ERR_INVALID.  All calls on one GPU share that array: calls that
+ * overlap on one GPU (threads, contexts) race; serialise them. */
+#define FS_LINES_STATIC_MAX 262144
+int fs_particle_lines_static(fs_ctx *ctx, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha);
 int fs_particles_reserve(fs_ctx *ctx, long capacity);
 int fs_set_particle_params(fs_ctx *ctx, const fs_particle_params *pp);
 
