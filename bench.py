@@ -258,6 +258,13 @@ def config4_extra(world, rank, local_rank, dist, frames=10, warm=4):
     out = {"grid": [W, H], "frames": frames, "pointers": 8}
     if world == 1:
         el = timed(0)
+        # the two Jacobi loops alone at this size (what roofline.kernels.*_16384 is computed from)
+        pl, pspl, psw = jacobi_microbench(s, W, H, reps=3)
+        dl, dspl, dsw = diffuse_microbench(s, W, H, reps=3)
+        out["jacobi"] = {"pressure_us_per_launch": pl * 1e3, "pressure_sweeps_per_launch": pspl,
+                         "diffuse_us_per_launch": dl * 1e3, "diffuse_sweeps_per_launch": dspl,
+                         "pressure_gcell_updates_per_s_per_sweep": W * H / (psw * 1e-3) / 1e9,
+                         "diffuse_gcell_updates_per_s_per_sweep": W * H / (dsw * 1e-3) / 1e9}
     else:
         # both slab plans, with every wait for halo rows timed (the event records cost ~1 us per join)
         s.set_profile(True)
@@ -284,17 +291,39 @@ def config4_extra(world, rank, local_rank, dist, frames=10, warm=4):
     return out
 
 
-def load_traffic(workload):
-    """HBM bytes per launch of the Jacobi kernel from the committed PMC passes (profiles/traffic.json,
-    collected on config 2 by scripts/profile_round.sh); null for any other workload."""
-    if workload != "config2":
-        return None
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+ROOFLINE_INPUTS = os.path.join("profiles", "roofline_inputs.json")
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); measured 67-73 T at the
+                                            # 2.31 GHz the chip holds under load: profiles/r02_valu_issue.log
+
+
+def load_roofline_inputs():
+    """PMC traffic + SQ counters of the two Jacobi kernels (scripts/profile_jacobi.sh + scripts/roofline_inputs.py).
+    They describe the kernels of ONE source tree: used only if its sha equals this tree's, else (None, reason)."""
+    from fluidsolver_amd.build import source_sha
     try:
-        with open(path) as f:
-            return json.load(f).get("k_jacobi_block_pressure_bytes_per_launch")
-    except Exception:
+        with open(os.path.join(ROOT, ROOFLINE_INPUTS)) as f:
+            ri = json.load(f)
+    except Exception as e:
+        return None, "%s unreadable: %s" % (ROOFLINE_INPUTS, e)
+    sha = source_sha()
+    if ri.get("source_sha") != sha:
+        return None, "%s was measured on kernel sources %s, this tree is %s: PMC-derived figures withheld" % (
+            ROOFLINE_INPUTS, ri.get("source_sha"), sha)
+    return ri, None
+
+
+def physical_roofline(ri, key, us_per_launch):
+    """What the launch really does to the memory system and the VALUs: PMC bytes / live launch time / 8 TB/s, and the
+    VALU pipe occupancy (busy quad-cycles x 4 / SIMD-cycles of the launch, 2.4 GHz nominal)."""
+    e = ri["kernels"].get(key)
+    if not e or not us_per_launch:
         return None
+    t = us_per_launch * 1e-6
+    return {"kernel": e["kernel"], "us_per_launch_live": us_per_launch, "us_per_launch_traced": e["traced_ns"] / 1e3,
+            "hbm_bytes_per_launch_pmc": e["hbm_bytes"], "hbm_GBps": e["hbm_bytes"] / t / 1e9,
+            "hbm_frac": e["hbm_bytes"] / t / (HBM_PEAK_GBS * 1e9),
+            "valu_busy_frac": e["sq"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (256 * 4 * t * 2.4e9),
+            "valu_insts_per_launch": e["sq"]["SQ_INSTS_VALU"], "valu_cycles_per_inst": e.get("valu_cycles_per_inst")}
 
 
 def main():
@@ -448,25 +477,31 @@ def main():
                                           "us_per_sweep": dsw * 1e3, "us_per_launch": dl * 1e3, "sweeps_per_launch": dspl,
                                           "effective_GBps": 16.0 * total_cells / (dsw * 1e-3) / 1e9,
                                           "note": "both velocity planes per sweep, 16 algorithmic B/cell/sweep"}
-        out["roofline"] = {"kernel": "k_jacobi_block<pressure> (%g sweeps/launch)" % sweeps_per_launch,
-                           "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                           "note": "achieved = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
-                                   "HIP-event launch time; temporal blocking keeps T sweeps on chip, so the "
-                                   "effective figure may exceed the HBM peak"}
-        # Second bound, the one that binds while the planes sit in the Infinity Cache: VALU issue.
-        # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-slots/s; a pressure sweep issues 6.3 slots per cell of the
-        # 256 x 64 register tile, of which (256 - 2 HX)(64 - 2 T) cells are stored (HX = T rounded up to 4).
-        T = int(sweeps_per_launch)
-        hx = (T + 3) // 4 * 4
-        stored = (256 - 2 * hx) * (64 - 2 * T) / (256.0 * 64.0)
-        if stored > 0:
-            issue_peak = 256 * 4 * 16 * 2.4e9
-            t_issue = 6.3 * total_cells / stored / issue_peak
-            out["roofline"]["valu_issue"] = {"slots_per_cell": 6.3, "stored_fraction_of_tile": stored,
-                                             "peak_lane_slots_per_s": issue_peak, "us_per_sweep_at_peak": t_issue * 1e6,
-                                             "frac": t_issue / (ms_sweep * 1e-3),
-                                             "note": "informational: fraction of the VALU issue rate the sweep reaches"}
+        # Contract fields: achieved = ALGORITHMIC bytes per launch / live launch time (the EFFECTIVE bandwidth: T
+        # sweeps share one pass over memory, so it may exceed the HBM peak and is NOT a fraction of any hardware
+        # limit).  The physical figures follow: hbm_frac (PMC bytes / live time / 8 TB/s) and valu_busy_frac.
+        ri, why = load_roofline_inputs()
+        roof = {"kernel": "k_jacobi_block<pressure> (%g sweeps/launch)" % sweeps_per_launch,
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "effective_GBps": achieved, "traffic": None,
+                "note": "achieved/frac/effective_GBps = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
+                        "HIP-event launch time: T sweeps share one pass over memory, so this is an effective figure "
+                        "and may exceed 1; hbm_frac = PMC bytes / launch time / 8 TB/s is the physical one"}
+        if ri is None:
+            roof["traffic_withheld"] = why
+        elif (W, H) == (3072, 3072):
+            kern = {"pressure_3072": physical_roofline(ri, "pressure_3072", ms_launch * 1e3),
+                    "diffuse_3072": physical_roofline(ri, "diffuse_3072", dl * 1e3)}
+            roof["traffic"] = kern["pressure_3072"]["hbm_bytes_per_launch_pmc"] if kern["pressure_3072"] else None
+            roof["hbm_frac"] = kern["pressure_3072"]["hbm_frac"] if kern["pressure_3072"] else None
+            roof["kernels"] = kern
+            roof["traffic_source"] = "%s (kernel sources %s)" % (ROOFLINE_INPUTS, ri["source_sha"])
+            roof["valu_issue"] = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                                  "frac": kern["pressure_3072"]["valu_busy_frac"] if kern["pressure_3072"] else None,
+                                  "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz): the share "
+                                          "of the launch in which the VALU pipes are occupied; instruction costs in "
+                                          "profiles/r02_valu_issue.log (SIMD-32: add/mul/fma 2 cycles, packed / DPP / fp64 4)"}
+        out["roofline"] = roof
         if not args.no_cpu_baseline and rank == 0:
             out["cpu_baseline"] = cpu_baseline(W, H, params)
             out["cpu_baseline_all_cores"] = cpu_baseline(W, H, params, budget_s=8.0, omp=True)
@@ -496,6 +531,11 @@ def main():
         try:
             s.close()
             out["config4_strong"] = config4_extra(world if slabs else 1, rank, local_rank, dist if slabs else None)
+            j16 = out["config4_strong"].get("jacobi")
+            if j16 and not slabs and out.get("roofline", {}).get("kernels") is not None:
+                ri, _ = load_roofline_inputs()
+                out["roofline"]["kernels"]["pressure_16384"] = physical_roofline(ri, "pressure_16384", j16["pressure_us_per_launch"])
+                out["roofline"]["kernels"]["diffuse_16384"] = physical_roofline(ri, "diffuse_16384", j16["diffuse_us_per_launch"])
         except Exception as e:   # the extra must never cost the main line
             out["config4_strong"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:

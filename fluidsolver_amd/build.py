@@ -19,6 +19,18 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fP
          "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
 
+def source_sha():
+    """sha256 over the kernel sources, headers and build flags: what a profile under profiles/ was measured on.
+    bench.py prints PMC-derived figures only when this matches the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS[:6]).encode())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
