@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ + TCC counter passes and a kernel trace of the two Jacobi loops alone (scripts/jacobi_loops.py), one run per pass.
-# usage: scripts/profile_jacobi.sh <tag> <size>     outputs under gpurun_out/jac_<tag>_<size>_*/
+# usage: [JL_ARGS="--variant 8 ..."] scripts/profile_jacobi.sh <tag> <size>     outputs under gpurun_out/jac_<tag>_<size>_*/
 set -e -o pipefail
 TAG=${1:-x}
 SIZE=${2:-3072}
@@ -10,7 +10,7 @@ P=jac_${TAG}_${SIZE}
 cd /tmp && export TMPDIR=/tmp
 run() {   # name, rocprofv3 options...
     local name=$1; shift
-    timeout -s KILL 150 rocprofv3 "$@" -f csv -d $OUT/${P}_$name -o j -- python3 $R/scripts/jacobi_loops.py --size $SIZE --reps 5 > $OUT/${P}_$name.log 2>&1
+    timeout -s KILL 150 rocprofv3 "$@" -f csv -d $OUT/${P}_$name -o j -- python3 $R/scripts/jacobi_loops.py --size $SIZE --reps 5 $JL_ARGS > $OUT/${P}_$name.log 2>&1
 }
 run trace --kernel-trace --stats
 run sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
