@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfluidsolver_hip.so")
+LIB_PROBE = os.path.join(HERE, "libfluidsolver_hip_probe.so")   # -DFS_PROBE: timing probes compiled in (scripts/ only)
 SOURCES = ["passes.hip", "jacobi.hip", "context.hip", "slab.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ctx.h"), os.path.join(ROOT, "include", "fluidsolver.h")]
 
@@ -39,16 +40,17 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
+def build(force=False, verbose=True, probe=False):
+    if not probe and not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    cmd = [hipcc] + FLAGS + (["-DFS_PROBE"] if probe else []) + ["-o", LIB_PROBE if probe else LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return LIB_PROBE if probe else LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, probe="--probe" in sys.argv)

@@ -47,7 +47,6 @@ struct JacobiArgs {
     int xcd_chunked;   // tile order, see the kernel
     int stagger;       // start delay of every other resident workgroup, 10 ns ticks (0 = off)
     int stagger_mode;
-    int ntx, nty, nplanes;   // persistent form: tiles per row / column of the launch's row range, planes
 };
 
 // x / den for a launch-constant den, bit-identical to the IEEE fp32 division the reference formula
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     // De-phase the workgroups that share a CU.  All workgroups of the first dispatch wave start together
     // and would all load, then all sweep, then all store: HBM idles while the VALUs run and vice versa.
     // Holding back every other resident workgroup by about one load phase lets one workgroup of a CU
-    // stream its tile while the other sweeps.  Timing only: results do not depend on it.
+    // stream its tile while the other sweeps.  Timing only: results do not depend on it (stagger modes 0..3).
     if (A.stagger > 0) {
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         bool late;
@@ -264,7 +263,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         rowfixed |= (rf ? 1u : 0u) << i;
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row_in_buf && col_in_buf && !(A.stagger_mode & 32)) {
+#ifdef FS_PROBE
+        const bool probe_no_loads = A.stagger_mode & 32;
+#else
+        const bool probe_no_loads = false;
+#endif
+        if (row_in_buf && col_in_buf && !probe_no_loads) {
             const size_t o = row_off(g, y) + gx;
             if (in) pv = ld4(in + o);
             if (OP == OP_PRESSURE && !PRO) dv = ld4(A.div + o);
@@ -309,8 +313,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         }
     }
 
+#ifdef FS_PROBE   // timing probes (scripts/jacobi_loops.py --probe): no sweeps / three times the sweeps / every tile through the edge path
     const int Trun = (A.stagger_mode & 16) ? 0 : (A.stagger_mode & 64) ? 3 * A.T : A.T;
     if (edge_tile || (A.stagger_mode & 128))
+#else
+    const int Trun = A.T;
+    if (edge_tile)
+#endif
         run_sweeps_tile<OP, R, NW, true>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
     else
         run_sweeps_tile<OP, R, NW, false>(p, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
@@ -376,228 +385,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent form (tile variants 8 and 9): ONE workgroup per CU walks over a list of tiles.
-//
-// What the counters say about the form above at 3072^2 (profiles/r02_a_sq_jacobi_3072.json): the VALU pipes are occupied
-// for 54 % (pressure) / 64 % (diffuse) of a launch; the rest is the load phase of every workgroup (nothing to overlap it
-// with but the ONE other workgroup of its CU, which started at the same time) and the per-sweep barrier.  Here
-//   * the workgroup is 8 waves of up to 256 VGPRs per lane (2 waves per SIMD, which still saturates the 4-cycle packed /
-//     DPP / fp64 instructions the sweeps are made of: profiles/r02_valu_issue.log), so the NEXT tile is loaded into registers of
-//     its own while the current one is swept, and the stores of a tile drain under the sweeps of the next one;
-//   * the sweeps ping-pong between two register tiles (no row is copied to stay alive), also for the pressure loop, whose
-//     second tile does not fit the 64 VGPRs of the two-workgroups-per-CU form;
-//   * the rows of a wave that need no other wave's data are swept BEFORE the barrier of the sweep and while the edge rows
-//     of the neighbours are read back, so a wave that arrives early has work left and the exchange latency is covered
-//     by the wave itself rather than by a second workgroup.
-// Per-cell arithmetic is sweep_row's: same bits as the form above and as T single sweeps.
-// ---------------------------------------------------------------------------------------------------------------
-struct TileGeom {
-    int gx, wy0;            // this lane's first column, this wave's first row (global)
-    size_t plane;           // float offset of the tile's plane
-    unsigned rowfixed;      // bit i: row i of the wave is a boundary row or outside the domain
-    bool col_in_buf, edge_tile, fx0, fx1, fx2, fx3;
-};
-
-template <int R, int NW>
-__device__ __forceinline__ TileGeom tile_geom(const JacobiArgs &A, unsigned t, int OW, int OH, int lane, int wave)
-{
-    const GK g = A.g;
-    const unsigned per_plane = (unsigned)A.ntx * (unsigned)A.nty;
-    const unsigned pl = t / per_plane, r = t - pl * per_plane;
-    const unsigned ty = r / (unsigned)A.ntx, tx = r - ty * (unsigned)A.ntx;
-    const int x0 = (int)tx * OW - A.HX;
-    const int ry0 = A.yb + (int)ty * OH - A.TE;
-    TileGeom tg;
-    tg.gx = x0 + 4 * lane;
-    tg.wy0 = ry0 + wave * R;
-    tg.plane = (size_t)pl * A.stride;
-    tg.col_in_buf = tg.gx >= 0 && tg.gx < g.pitch;
-    tg.fx0 = (tg.gx + 0) <= 0 || (tg.gx + 0) >= g.W - 1;
-    tg.fx1 = (tg.gx + 1) <= 0 || (tg.gx + 1) >= g.W - 1;
-    tg.fx2 = (tg.gx + 2) <= 0 || (tg.gx + 2) >= g.W - 1;
-    tg.fx3 = (tg.gx + 3) <= 0 || (tg.gx + 3) >= g.W - 1;
-    tg.edge_tile = x0 <= 0 || x0 + 256 >= g.W - 1 || ry0 <= 0 || ry0 + NW * R >= g.H - 1;
-    unsigned rf = 0;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int y = tg.wy0 + i;
-        rf |= ((y <= 0 || y >= g.H - 1) ? 1u : 0u) << i;
-    }
-    tg.rowfixed = rf;
-    return tg;
-}
-
-// PZ: the input iterate is all zero (first launch of a pressure loop: the clearTexture of Solver:528-530 folded in)
-template <int OP, int R, bool PZ>
-__device__ __forceinline__ void load_tile(const JacobiArgs &A, const TileGeom &tg, float4 (&pv)[R], float4 (&dv)[R])
-{
-    const GK g = A.g;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int y = tg.wy0 + i;
-        pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= g.y0 && y < g.y0 + g.rows && tg.col_in_buf && !(A.stagger_mode & 32)) {
-            const size_t o = row_off(g, y) + tg.gx;
-            if (!PZ) pv[i] = ld4(A.in + tg.plane + o);
-            if (OP == OP_PRESSURE) dv[i] = ld4(A.div + o);
-        }
-    }
-}
-
-template <int OP, bool EDGE>
-__device__ __forceinline__ Row updated_row(const Row &c, const Row &up, const Row &dn, const Row &d, bool rowfix, bool fx0,
-                                           bool fx1, bool fx2, bool fx3, float a, double rden)
-{
-    Row n = sweep_row<OP>(c, up, dn, d, a, rden);
-    if (EDGE) {
-        // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
-        const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
-        if (fx0) n.a.x = fixedv.a.x;
-        if (fx1) n.a.y = fixedv.a.y;
-        if (fx2) n.b.x = fixedv.b.x;
-        if (fx3) n.b.y = fixedv.b.y;
-        if (rowfix) n = fixedv;
-    }
-    return n;
-}
-
-// One sweep src -> dst.  The edge rows of src are already in xch[buf]; the edge rows of dst go to xch[buf ^ 1].
-template <int OP, int R, int NW, bool EDGE>
-__device__ __forceinline__ void sweep_split(const Row (&src)[R], Row (&dst)[R], const Row (&d)[R], float4 (*xch)[NW][2][64],
-                                            int buf, int lane, int wave, int wup, int wdn, unsigned rowfixed, bool fx0,
-                                            bool fx1, bool fx2, bool fx3, float a, double rden)
-{
-    constexpr int MID = R / 2;
-#pragma unroll
-    for (int i = 1; i < MID; ++i)       // rows that need nobody else: before the barrier
-        dst[i] = updated_row<OP, EDGE>(src[i], src[i - 1], src[i + 1], d[i], (rowfixed >> i) & 1u, fx0, fx1, fx2, fx3, a, rden);
-    // (the scheduling fences keep this order: left alone, the compiler pulls the first edge row up to a dozen instructions
-    // behind the reads and every wave sits out the LDS latency, which two waves per SIMD cannot cover)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    const float4 above4 = xch[buf][wup][1][lane];    // row above this wave's strip
-    const float4 below4 = xch[buf][wdn][0][lane];    // row below it
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = MID; i < R - 1; ++i)   // ... and while the two reads are in flight
-        dst[i] = updated_row<OP, EDGE>(src[i], src[i - 1], src[i + 1], d[i], (rowfixed >> i) & 1u, fx0, fx1, fx2, fx3, a, rden);
-    __builtin_amdgcn_sched_barrier(0);
-    dst[0] = updated_row<OP, EDGE>(src[0], row_of(above4), src[1], d[0], rowfixed & 1u, fx0, fx1, fx2, fx3, a, rden);
-    dst[R - 1] = updated_row<OP, EDGE>(src[R - 1], src[R - 2], row_of(below4), d[R - 1], (rowfixed >> (R - 1)) & 1u, fx0, fx1,
-                                       fx2, fx3, a, rden);
-    xch[buf ^ 1][wave][0][lane] = f4_of(dst[0]);
-    xch[buf ^ 1][wave][1][lane] = f4_of(dst[R - 1]);
-}
-
-// T sweeps that always END in q: p -> q first when T is odd, then pairs q -> p -> q.  The caller has the tile in p (T odd) or
-// in q (T even) and its edge rows in xch[0].
-template <int OP, int R, int NW, bool EDGE>
-__device__ __forceinline__ void run_sweeps_split(Row (&p)[R], Row (&q)[R], const Row (&d)[R], float4 (*xch)[NW][2][64], int T,
-                                                 int lane, int wave, unsigned rowfixed, bool fx0, bool fx1, bool fx2, bool fx3,
-                                                 float a, double rden)
-{
-    const int wup = wave > 0 ? wave - 1 : 0;            // tile rim rows have no neighbour: any value, never used
-    const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
-    int s = 0, buf = 0;
-    if (T & 1) {
-        sweep_split<OP, R, NW, EDGE>(p, q, d, xch, 0, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
-        s = 1;
-        buf = 1;
-    }
-    for (; s < T; s += 2) {
-        sweep_split<OP, R, NW, EDGE>(q, p, d, xch, buf, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
-        sweep_split<OP, R, NW, EDGE>(p, q, d, xch, buf ^ 1, lane, wave, wup, wdn, rowfixed, fx0, fx1, fx2, fx3, a, rden);
-    }
-}
-
-template <int R, int NW>
-__device__ __forceinline__ void store_tile(const JacobiArgs &A, const TileGeom &tg, const Row (&res)[R], int lane, int wave)
-{
-    const GK g = A.g;
-    const bool col_out = 4 * lane >= A.HX && 4 * lane < 256 - A.HX && tg.col_in_buf;
-    if (col_out) {
-        float *out = A.out + tg.plane;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int ty = wave * R + i;
-            const int y = tg.wy0 + i;
-            if (ty >= A.T && ty < NW * R - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + tg.gx, f4_of(res[i]));
-        }
-    }
-}
-
-// Order inside the tile loop, chosen so that no wait ever covers a younger memory operation (vmcnt counts in issue
-// order): wait for the loads of tile k (issued a whole tile ago) -> only then issue the stores of tile k - 1 -> issue the
-// loads of tile k + 1 -> sweep tile k.  The stores and the loads drain under the sweeps.
-// NW = 8 waves of R rows: two waves per SIMD, up to 256 VGPRs per lane -- room for two tiles, the divergence and the whole
-// next tile (the 16-wave form at 128 VGPRs spilled the prefetched rows, and a spill is a wait for the prefetch).
-template <int OP, int R, int NW, bool PZ>
-__global__ __launch_bounds__(NW * 64, NW / 4) void k_jacobi_persist(JacobiArgs A)
-{
-    __shared__ float4 xch[2][NW][2][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int OW = 256 - 2 * A.HX;
-    const int OH = NW * R - 2 * A.TE;
-    // this workgroup's tiles: first, first + step, ... (count of them).  Chunked: the workgroups of one XCD (blockIdx % 8,
-    // observed placement, speed only) share one contiguous run of the (plane, y, x) tile order, so overlapping rims hit in
-    // that XCD's L2; plain: round-robin over the whole launch.
-    const unsigned total = (unsigned)A.ntx * (unsigned)A.nty * (unsigned)A.nplanes;
-    unsigned first, step, count;
-    if (A.xcd_chunked) {
-        const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3, per = gridDim.x >> 3;
-        const unsigned q = total >> 3, r = total & 7u;
-        const unsigned start = xcd * q + (xcd < r ? xcd : r), len = q + (xcd < r ? 1u : 0u);
-        first = start + idx;
-        step = per;
-        count = idx < len ? (len - idx + per - 1) / per : 0;
-    } else {
-        first = blockIdx.x;
-        step = gridDim.x;
-        count = first < total ? (total - first + step - 1) / step : 0;
-    }
-    if (count == 0) return;
-
-    // (tile geometry is recomputed from the tile index where it is needed -- a few dozen integer instructions per tile --
-    // rather than kept in registers across the sweeps)
-    float4 npv[R], ndv[R];
-    load_tile<OP, R, PZ>(A, tile_geom<R, NW>(A, first, OW, OH, lane, wave), npv, ndv);
-    Row q[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) q[i] = Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-    for (unsigned k = 0; k < count; ++k) {
-        const unsigned t = first + k * step;
-        Row p[R], d[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            p[i] = row_of(npv[i]);
-            d[i] = row_of(ndv[i]);
-            // the tile is in registers HERE (forces the wait for its loads ahead of the stores and loads issued below)
-            asm volatile("" : "+v"(p[i].a), "+v"(p[i].b));
-            if (OP == OP_PRESSURE) asm volatile("" : "+v"(d[i].a), "+v"(d[i].b));
-        }
-        if (k > 0) store_tile<R, NW>(A, tile_geom<R, NW>(A, t - step, OW, OH, lane, wave), q, lane, wave);
-        if (k + 1 < count)     // the next tile streams in under the sweeps of this one
-            load_tile<OP, R, PZ>(A, tile_geom<R, NW>(A, t + step, OW, OH, lane, wave), npv, ndv);
-        const TileGeom cur = tile_geom<R, NW>(A, t, OW, OH, lane, wave);
-        if (!(A.T & 1)) {
-#pragma unroll
-            for (int i = 0; i < R; ++i) q[i] = p[i];
-        }
-        __syncthreads();       // every wave has read the last exchange rows of the previous tile
-        xch[0][wave][0][lane] = f4_of(p[0]);
-        xch[0][wave][1][lane] = f4_of(p[R - 1]);
-        const int Trun = (A.stagger_mode & 16) ? (A.T & 1) : (A.stagger_mode & 64) ? 3 * A.T : A.T;
-        if (cur.edge_tile || (A.stagger_mode & 128))
-            run_sweeps_split<OP, R, NW, true>(p, q, d, xch, Trun, lane, wave, cur.rowfixed, cur.fx0, cur.fx1, cur.fx2, cur.fx3, A.a, A.rden);
-        else
-            run_sweeps_split<OP, R, NW, false>(p, q, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
-    }
-    store_tile<R, NW>(A, tile_geom<R, NW>(A, first + (count - 1) * step, OW, OH, lane, wave), q, lane, wave);
-}
-
 // tuning knobs (process-wide; see fs_config_set)
 // From the 3072^2 sweeps in profiles/r01_tune_jacobi*.log.  Depths: the pressure sweep is cheap per cell, so
 // fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
@@ -623,37 +410,6 @@ static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, h
     else
         hipLaunchKernelGGL((k_jacobi_block<OP, R, NW, MINW, false, false>), grid, dim3(NW * 64), 0, stream, A);
     FS_LAUNCH_CHECK("k_jacobi_block");
-    return FS_OK;
-}
-
-static int cu_count()
-{
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
-}
-
-template <int OP, int R, int NW>
-static int launch_persist(const JacobiArgs &A0, const fs_grid *g, int nplanes, hipStream_t stream)
-{
-    JacobiArgs A = A0;
-    const int OW = 256 - 2 * A.HX, OH = NW * R - 2 * A.TE;
-    if (OH < 1) { set_error("jacobi: block depth %d too deep for a %d-row tile", A.T, NW * R); return FS_ERR_INVALID; }
-    A.ntx = (g->width + OW - 1) / OW;
-    A.nty = (A.ye - A.yb + OH - 1) / OH;
-    A.nplanes = nplanes;
-    const long total = (long)A.ntx * A.nty * nplanes;
-    long wgs = cu_count();                       // one workgroup per CU
-    if (total < wgs) wgs = (total + 7) / 8 * 8;  // a multiple of 8 keeps the per-XCD split of the chunked order simple
-    if (OP == OP_PRESSURE && !A.in)
-        hipLaunchKernelGGL((k_jacobi_persist<OP, R, NW, OP == OP_PRESSURE>), dim3((unsigned)wgs), dim3(NW * 64), 0, stream, A);
-    else
-        hipLaunchKernelGGL((k_jacobi_persist<OP, R, NW, false>), dim3((unsigned)wgs), dim3(NW * 64), 0, stream, A);
-    FS_LAUNCH_CHECK("k_jacobi_persist");
     return FS_OK;
 }
 
@@ -686,16 +442,7 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.stagger_mode = g_stagger_mode;
     // p in, p out and div of the rows in play, against ~3/4 of the 256 MiB Infinity Cache
     A.xcd_chunked = OP == OP_PRESSURE && 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) < 192.0 * 1024 * 1024;
-    const int variant = g_tile_variant[OP];
-    if (variant >= 8 && !gu && !du) {   // persistent form (plain launches; the projection's first / last launch keep the form above)
-        A.xcd_chunked = 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) * (OP == OP_PRESSURE ? 1 : nplanes) < 192.0 * 1024 * 1024;
-        if constexpr (OP == OP_DIFFUSE)
-            if (variant == 10) return launch_persist<OP, 4, 16>(A, g, nplanes, stream);                   // 16 waves x 4 rows
-        if constexpr (OP == OP_DIFFUSE)
-            if (variant == 9) return launch_persist<OP, 12, 8>(A, g, nplanes, stream);                    // 256 x 96 tile
-        return launch_persist<OP, 8, 8>(A, g, nplanes, stream);                                           // 256 x 64 tile
-    }
-    switch (variant) {
+    switch (g_tile_variant[OP]) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
     case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
@@ -769,7 +516,7 @@ int config_set_block_depth(int op, int v)   // op < 0: both loops
 int config_get_block_depth(int op) { return g_block_depth[op == 1 ? 1 : 0]; }
 int config_set_tile_variant(int op, int v)   // op < 0: both loops
 {
-    if (v < 0 || v > 10 || op > 1) return FS_ERR_INVALID;
+    if (v < 0 || v > 7 || op > 1) return FS_ERR_INVALID;
     if (op < 0) g_tile_variant[0] = g_tile_variant[1] = v;
     else g_tile_variant[op] = v;
     return FS_OK;
@@ -777,6 +524,9 @@ int config_set_tile_variant(int op, int v)   // op < 0: both loops
 int config_get_tile_variant(int op) { return g_tile_variant[op == 1 ? 1 : 0]; }
 int config_set_stagger(int ticks, int mode)
 {
+#ifndef FS_PROBE
+    if (mode > 3) return FS_ERR_INVALID;   // modes 0..3 choose which workgroups start late; higher bits exist in probe builds only
+#endif
     if (ticks >= 0) g_stagger = ticks;
     if (mode >= 0) g_stagger_mode = mode;
     return FS_OK;

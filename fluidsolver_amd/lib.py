@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfluidsolver_hip.so")
+# FS_PROBE_LIB=1 (measurement scripts only): the -DFS_PROBE build with the timing probes compiled in
+LIB_PATH = os.path.join(HERE, "libfluidsolver_hip_probe.so" if os.environ.get("FS_PROBE_LIB") == "1" else "libfluidsolver_hip.so")
 
 FS_OK = 0
 COMM_ID_BYTES = 128

@@ -18,7 +18,7 @@ if __name__ == "__main__":
     ap.add_argument("--variant-diffuse", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=0, help="block depth of the pressure loop (0: library default)")
     ap.add_argument("--depth-diffuse", type=int, default=0)
-    ap.add_argument("--probe", type=int, default=0, help="FS_OPT_STAGGER_MODE bits (16: no sweeps, 32: no loads): timing only, wrong fields")
+    ap.add_argument("--probe", type=int, default=0, help="FS_OPT_STAGGER_MODE bits of the FS_PROBE build (FS_PROBE_LIB=1; 16: no sweeps, 32: no loads, 64: 3x the sweeps, 128: edge path everywhere): timing only, wrong fields")
     a = ap.parse_args()
     import bench
     from fluidsolver_amd import lib as L

@@ -246,8 +246,8 @@ def test_block_depth_does_not_change_bits(lib, oracle, depth):
         lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
-@pytest.mark.parametrize("depth", [1, 4, 5, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("depth", [1, 5, 10])
 def test_every_tile_variant_matches_the_oracle(lib, oracle, variant, depth):
     # every register-tile shape (rows per lane x waves) of the blocked kernel, both loops, edge and interior tiles
     from fluidsolver_amd import lib as L
@@ -278,53 +278,6 @@ def test_every_tile_variant_matches_the_oracle(lib, oracle, variant, depth):
         assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], a)
         da, db = dev_planes(vel), dev_planes(np.zeros_like(vel))
         ok(lib.fs_k_diffuse_n(C.byref(g), ptr(da), ptr(db), 2, da.stride(0), 1.5e-4, 0.5, n, C.byref(in_b), stream()))
-        sync()
-        assert np.array_equal(host_planes(db if in_b.value else da, W), va)
-    finally:
-        lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, old[0]); lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, old[1])
-        lib.fs_config_set(L.OPT_TILE_VARIANT, old[2])
-
-
-@pytest.mark.parametrize("variant,depth", [(8, 10), (8, 7), (9, 8), (9, 5)])
-def test_persistent_form_many_tiles_per_workgroup(lib, oracle_omp, variant, depth):
-    # the persistent form (one workgroup per CU walking a list of tiles, next tile prefetched under the sweeps): a grid of
-    # more tiles than CUs, so every workgroup runs its tile loop several times; odd and even depths (the last launch of
-    # n = 23 is short), pressure from zero and from a given iterate, three diffuse planes
-    from fluidsolver_amd import lib as L
-    from gpu_util import dev_planes, grid, host_planes, ptr, stream, sync
-    from oracle_binding import full_grid
-    W, H, n = 2900, 2300, 23
-    div = rnd((H, W), 31, -1, 1)
-    p0 = rnd((H, W), 32, -1, 1)
-    dye = rnd((3, H, W), 33, -2, 2)
-    og = full_grid(W, H)
-    exp = []
-    for start in (np.zeros((H, W), F), p0):
-        a, b = start.copy(), np.zeros((H, W), F)
-        for _ in range(n):
-            oracle_omp.pressureSolve(og, div, a, b)
-            a, b = b, a
-        exp.append(a)
-    va, vb = dye.copy(), np.zeros_like(dye)
-    for _ in range(n):
-        for pl in range(3):
-            oracle_omp.diffuse(og, va[pl], vb[pl], 1.5e-4, 0.5)
-        va, vb = vb, va
-    old = (lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE), lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE),
-           lib.fs_config_get(L.OPT_TILE_VARIANT))
-    try:
-        ok(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
-        ok(lib.fs_config_set(L.OPT_TILE_VARIANT, variant))
-        g = grid(W, H)
-        dd = dev_planes(div)
-        in_b = C.c_int(-1)
-        for zero, start, e in ((1, np.full((H, W), 7.0, F), exp[0]), (0, p0, exp[1])):
-            pa, pb = dev_planes(start), dev_planes(np.full((H, W), 9.0, F))
-            ok(lib.fs_k_pressureSolve_n(C.byref(g), ptr(dd), ptr(pa), ptr(pb), n, zero, C.byref(in_b), stream()))
-            sync()
-            assert np.array_equal(host_planes(pb if in_b.value else pa, W)[0], e)
-        da, db = dev_planes(dye), dev_planes(np.zeros_like(dye))
-        ok(lib.fs_k_diffuse_n(C.byref(g), ptr(da), ptr(db), 3, da.stride(0), 1.5e-4, 0.5, n, C.byref(in_b), stream()))
         sync()
         assert np.array_equal(host_planes(db if in_b.value else da, W), va)
     finally:
