@@ -100,6 +100,7 @@ def make_single(W, H, params, particles):
         # mass ~ U(0.1,1), life ~ U(0.3,1), age = 0
         ps.set_arrays(fill(0, W, 0x9E3779B9), fill(0, H, 0x9E3779B9 ^ 1), z, z, fill(0.3, 1.0, 0x9E3779B9 ^ 2),
                       fill(0.1, 1.0, 0x9E3779B9 ^ 3), z)
+        ps.stepWithSolver((W, H))   # the tracer update is the last node of the frame's graph
     return s, ps
 
 
@@ -108,9 +109,7 @@ def frame_single(s, ps, f, W, H, n_pointers=1):
     for ptr in range(n_pointers):
         pos, force, col = splat(W, H, f, ptr, n_pointers)
         s.applyForce(pos, force, col)
-    s.update()
-    if ps is not None:
-        ps.update(s, (W, H))
+    s.update()   # with tracers: FluidSolver.update() + ParticleSystem.update() (MetalView.swift:152-155) in one graph
 
 
 def jacobi_microbench(s, W, H, sweeps=40, reps=25):

@@ -323,7 +323,7 @@ int fs_destroy(fs_ctx *c)
     (void)hipFree(c->display); (void)hipFree(c->err_flag); (void)hipFree(c->cfl_dev);
     if (c->cfl_host) (void)hipHostFree(c->cfl_host);
     for (int i = 0; i < 7; ++i) { (void)hipFree(c->part[i]); (void)hipFree(c->part_t[i]); (void)hipFree(c->outbox[i]); }
-    (void)hipFree(c->tr_counts_dev); (void)hipFree(c->tr_matrix_dev);
+    (void)hipFree(c->tr_counts_dev); (void)hipFree(c->tr_matrix_dev); (void)hipFree(c->spawn_sums);
     if (c->tr_counts_host) (void)hipHostFree(c->tr_counts_host);
     if (c->tr_matrix_host) (void)hipHostFree(c->tr_matrix_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -672,6 +672,46 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
 }
 
 long fs_particles_count(fs_ctx *c) { return c ? c->n_particles : 0; }
+
+// ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on the device.  The reference's array holds the live
+// tracers in age order; `count` appends with removeFirst() at the cap (:196-199) leave the last `cap` of (live + new).
+// Here: count the live slots, drop the dead ones and the oldest that do not fit (order kept), write the new tracers
+// behind them.  Blocking (the live count comes back to the host, like the reference's particleCount, :229).
+int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, unsigned seed)
+{
+    CTX(c);
+    SINGLE(c, "fs_particles_spawn");
+    if (count < 0) { fs::set_error("negative spawn count"); return ctx_fail(c, FS_ERR_INVALID); }
+    const long cap = c->max_particles, n = c->n_particles;
+    if (cap == 0) return FS_OK;   // (count == 0 still drops the dead slots: the reference's array never holds any)
+    if (!c->part_t[0])
+        for (int i = 0; i < 7; ++i) TRYHIP(c, hipMalloc((void **)&c->part_t[i], (size_t)cap * sizeof(float)));
+    const long nb = fs::tracer_blocks(cap);
+    if (c->spawn_sums_cap < nb + 1) {
+        (void)hipFree(c->spawn_sums);
+        c->spawn_sums = nullptr; c->spawn_sums_cap = 0;
+        TRYHIP(c, hipMalloc((void **)&c->spawn_sums, (size_t)(nb + 1) * sizeof(int)));
+        c->spawn_sums_cap = nb + 1;
+    }
+    long live = 0;
+    if (n > 0) {
+        TRY(c, fs::tracer_count_live(n, c->part[4], c->spawn_sums, c->stream));
+        int total = 0;
+        TRYHIP(c, hipMemcpyAsync(&total, c->spawn_sums + fs::tracer_blocks(n), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        TRYHIP(c, hipStreamSynchronize(c->stream));
+        live = total;
+    }
+    const long after = std::min(cap, live + count);                   // Part:229 particleCount
+    const long drop = std::max(0L, live + count - cap);               // oldest tracers pushed out at the cap, :196-199
+    const long kept = live - std::min(drop, live);
+    if (n > 0) TRY(c, fs::tracer_compact(n, c->part, c->part_t, c->spawn_sums, drop, c->stream));
+    const long j0 = std::max(0L, count - cap);                        // more new tracers than slots: the first ones are pushed out too
+    TRY(c, fs::tracer_spawn(kept, j0, count, c->part_t, x, y, radius, seed, c->stream));
+    for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+    c->n_particles = after;
+    if (c->with_particles) drop_graphs(c);   // array pointers and the count are baked into the tracer node
+    return FS_OK;
+}
 
 int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha)
 {

@@ -137,6 +137,8 @@ struct fs_ctx {
     float *tr_matrix_host = nullptr;    // pinned
     std::vector<long> tr_send_off, tr_recv_cnt;
     long stat_migrated = 0;
+    int *spawn_sums = nullptr;          // fs_particles_spawn: live counts per block of 256 slots, then their scan (blocks + 1 ints)
+    long spawn_sums_cap = 0;
     float *lines_scratch = nullptr;     // this device's copy of the static staging array (fs_particle_lines_static); not owned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // fs_timer_*
     char error[512] = "";
@@ -146,6 +148,12 @@ namespace fs {
 
 int ctx_fail(fs_ctx *c, int rc);
 fs_grid grid_of(const fs_ctx *c, int depth);
+
+// tracer spawning (passes.hip)
+long tracer_blocks(long n);
+int tracer_count_live(long n, const float *life, int *sums, hipStream_t st);
+int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, hipStream_t st);
+int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, hipStream_t st);
 
 // frame planner (slab.hip)
 void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient (+ the CFL reduction on slabs);

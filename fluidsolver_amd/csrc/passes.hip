@@ -632,6 +632,81 @@ __global__ __launch_bounds__(256) void k_tracer_scatter(GK g, fs_particle_params
     for (int f = 0; f < 7; ++f) to.a[f][slot] = in.a[f][i];
 }
 
+// ---------------------------------------------------------------------------
+// Spawning, ParticleSystem.addParticles Part:186-231.  The reference's array holds the live tracers in age order and
+// appends with removeFirst() at the cap, i.e. it keeps the last `cap` of (live + new).  Here the arrays keep dead
+// slots until the next spawn, which (1) counts the live tracers per block of 256, (2) scans the counts, (3) copies the
+// live tracers, in order, minus the `drop` oldest, to the partner arrays and (4) writes the new ones behind them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tracer_live_count(long n, const float *__restrict__ life, int *__restrict__ block_sums)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n && life[i] != 0.0f;
+    const int cnt = __popcll(__ballot(live));
+    __shared__ int w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+// one wave: exclusive scan of sums[0..nb) in place, total to sums[nb]
+__global__ __launch_bounds__(64) void k_tracer_scan(int nb, int *sums)
+{
+    const int lane = threadIdx.x;
+    const int seg = (nb + 63) / 64;
+    const int lo = min(lane * seg, nb), hi = min(lo + seg, nb);
+    int mine = 0;
+    for (int i = lo; i < hi; ++i) mine += sums[i];
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    int run = incl - mine;
+    for (int i = lo; i < hi; ++i) { const int t = sums[i]; sums[i] = run; run += t; }
+    if (lane == 63) sums[nb] = incl;
+}
+__global__ __launch_bounds__(256) void k_tracer_compact(long n, TracerArrays in, TracerArrays out, const int *__restrict__ block_off,
+                                                        long drop)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n && in.a[4][i] != 0.0f;
+    const unsigned long long b = __ballot(live);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int w[4];
+    if (lane == 0) w[wv] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int k = 0; k < wv; ++k) base += w[k];
+    const long rank = (long)base + __popcll(b & ((1ull << lane) - 1ull));   // position among the live tracers, age order kept
+    if (live && rank >= drop) {
+#pragma unroll
+        for (int f = 0; f < 7; ++f) out.a[f][rank - drop] = in.a[f][i];
+    }
+}
+__device__ __forceinline__ float spawn_draw(unsigned &x, float lo, float hi)
+{
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const float r01 = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return lo + (hi - lo) * r01;
+}
+// new tracer j (j0 <= j < count) -> slot first + (j - j0); its four draws from an xorshift32 stream of its own
+__global__ __launch_bounds__(256) void k_tracer_spawn(long first, long j0, long count, TracerArrays out, float x, float y,
+                                                      float radius, unsigned seed)
+{
+    const long j = j0 + (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= count) return;
+    unsigned st = seed ^ ((unsigned)(j + 1) * 0x9E3779B9u);
+    if (!st) st = 1u;
+    const float ox = spawn_draw(st, -radius, radius);      // Part:202-205
+    const float oy = spawn_draw(st, -radius, radius);
+    const float alpha = spawn_draw(st, 0.3f, 1.0f);        // Part:211
+    const float ms = spawn_draw(st, 0.1f, 1.0f);           // Part:212
+    const long s = first + (j - j0);
+    out.a[0][s] = x + ox; out.a[1][s] = y + oy;            // Part:218
+    out.a[2][s] = 0.0f; out.a[3][s] = 0.0f;                // Part:208
+    out.a[4][s] = alpha; out.a[5][s] = ms; out.a[6][s] = 0.0f;   // Part:221-223
+}
+
 // max |plane| over rows [yb,ye): wave shuffle reduce, one atomicMax per wave (non-negative
 // floats order like their bit patterns).
 __global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const float *__restrict__ p, unsigned *out)
@@ -656,6 +731,34 @@ static inline dim3 quad_grid(const fs_grid *g, int nplanes)
     return dim3((qx + BX - 1) / BX, xcd_pad_rows((g->ye - g->yb + BY - 1) / BY, XCD_BAND), nplanes);
 }
 static const dim3 kBlock(BX, BY, 1);
+
+// spawn helpers for the context (context.hip); sums holds blocks + 1 ints
+long tracer_blocks(long n) { return (n + 255) / 256; }
+int tracer_count_live(long n, const float *life, int *sums, hipStream_t st)
+{
+    const long nb = tracer_blocks(n);
+    hipLaunchKernelGGL(k_tracer_live_count, dim3((unsigned)nb), dim3(256), 0, st, n, life, sums);
+    hipLaunchKernelGGL(k_tracer_scan, dim3(1), dim3(64), 0, st, (int)nb, sums);
+    FS_LAUNCH_CHECK("k_tracer_live_count / k_tracer_scan");
+    return FS_OK;
+}
+int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, hipStream_t st)
+{
+    TracerArrays a, b;
+    for (int f = 0; f < 7; ++f) { a.a[f] = in[f]; b.a[f] = out[f]; }
+    hipLaunchKernelGGL(k_tracer_compact, dim3((unsigned)tracer_blocks(n)), dim3(256), 0, st, n, a, b, sums, drop);
+    FS_LAUNCH_CHECK("k_tracer_compact");
+    return FS_OK;
+}
+int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, hipStream_t st)
+{
+    if (count <= j0) return FS_OK;
+    TracerArrays b;
+    for (int f = 0; f < 7; ++f) b.a[f] = out[f];
+    hipLaunchKernelGGL(k_tracer_spawn, dim3((unsigned)((count - j0 + 255) / 256)), dim3(256), 0, st, first, j0, count, b, x, y, radius, seed);
+    FS_LAUNCH_CHECK("k_tracer_spawn");
+    return FS_OK;
+}
 
 }  // namespace fs
 

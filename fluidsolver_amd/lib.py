@@ -107,6 +107,7 @@ SIGNATURES = {
     "fs_default_particle_params": (_i, [C.POINTER(ParticleParams), _f, _f]),
     "fs_particles_update": (_i, [_p, C.POINTER(ParticleParams)]),
     "fs_particles_count": (_l, [_p]),
+    "fs_particles_spawn": (_i, [_p, _f, _f, _l, _f, C.c_uint]),
     "fs_particles_reserve": (_i, [_p, _l]),
     "fs_particle_lines": (_i, [_p, _f, _f, _f, _p, _p]),
     "fs_particle_lines_static": (_i, [_p, _f, _f, _f, _p, _p]),

@@ -10,6 +10,8 @@ from collections import namedtuple
 import numpy as np
 
 F = np.float32
+# Swift's Float.pi is pi rounded TOWARD ZERO (0x40490FDA = 3.14159250...), not the nearest float (0x40490FDB)
+FLOAT_PI = np.array([0x40490FDA], dtype=np.uint32).view(np.float32)[0]
 
 FluidPreset = namedtuple("FluidPreset", "name viscosity diffusion deltaTime vorticityStrength fadeSpeed "
                                         "solverIterations forceMultiplier colorMultiplier brightness "
@@ -60,7 +62,7 @@ def _sin(x):
 def palette_color(palette, time):
     """ColorPalette.getColor(for:), ColorPalette.swift:40-95.  `time` in [0,1)."""
     t = F(time)
-    pi = F(math.pi)
+    pi = FLOAT_PI
     if palette == "Rainbow":
         return hsb_to_rgb(t, 1.0, 1.0)
     if palette == "Ocean":

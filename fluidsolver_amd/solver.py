@@ -224,21 +224,15 @@ class ParticleSystem:
         L.check(self._lib.fs_particles_get(self._solver.ctx, n, *ptrs), self._solver.ctx)
         return arrs
 
-    def addParticles(self, at, count=10, windowSize=None):  # :186-231
+    def addParticles(self, at, count=10, windowSize=None, seed=None):  # :186-231
+        """Spawns on the device (fs_particles_spawn).  `seed` replaces the system RNG of the reference (Float.random,
+        :203-212); by default every call takes the next number of this object's own seeded stream."""
         if not self.isEnabled:
             return
-        cur = self.get_arrays() if self.particleCount else [np.zeros(0, F) for _ in range(7)]
-        alive = cur[4] != 0     # compact dead slots on spawn
-        cur = [a[alive] for a in cur]
-        r = F(self.spawnRadius)
-        off = self._rng.uniform(-r, r, (count, 2)).astype(F)       # :202-205
-        alpha = self._rng.uniform(0.3, 1.0, count).astype(F)      # :211
-        mass = self._rng.uniform(0.1, 1.0, count).astype(F)       # :212
-        new = [F(at[0]) + off[:, 0], F(at[1]) + off[:, 1], np.zeros(count, F), np.zeros(count, F), alpha, mass,
-               np.zeros(count, F)]
-        cap = self._solver.max_particles
-        merged = [np.concatenate([a, b])[-cap:] for a, b in zip(cur, new)]   # :196-199 oldest dropped first
-        self.set_arrays(*merged)
+        if seed is None:
+            seed = int(self._rng.integers(1, 2 ** 32))
+        L.check(self._lib.fs_particles_spawn(self._solver.ctx, float(at[0]), float(at[1]), int(count),
+                                             float(self.spawnRadius), int(seed) & 0xFFFFFFFF), self._solver.ctx)
 
     def _pparams(self, windowSize):
         return L.ParticleParams(self.momentum, self.fluidForce, self.fluidDecayRate, 1 if self.linkToViscosity else 0,
@@ -252,6 +246,17 @@ class ParticleSystem:
             windowSize = (s.scaledWidth, s.scaledHeight)
         pp = self._pparams(windowSize)
         L.check(self._lib.fs_particles_update(s.ctx, C.byref(pp)), s.ctx)
+
+    def stepWithSolver(self, windowSize=None, on=True):
+        """Coordinator.draw calls FluidSolver.update() and then ParticleSystem.update() every frame (MetalView.swift:150-156).
+        With this on, FluidSolver.update() does both: the tracer update becomes the last node of the frame's graph
+        (FS_OPT_WITH_PARTICLES) instead of a launch of its own.  Call again after changing a tracer parameter."""
+        s = self._solver
+        if windowSize is None:
+            windowSize = (s.scaledWidth, s.scaledHeight)
+        pp = self._pparams(windowSize)
+        L.check(self._lib.fs_set_particle_params(s.ctx, C.byref(pp)), s.ctx)
+        s.set_option(L.OPT_WITH_PARTICLES, 1 if on else 0)
 
     def lineVertices(self, viewportSize, particleScale=None):
         """What render(in:viewportSize:) draws (:341-363 -> particleVertex, Shaders:446-476): per tracer the line

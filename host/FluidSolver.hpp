@@ -190,6 +190,14 @@ class ParticleSystem {
                                   mass.data(), age.data());
         if (rc) throw Error(rc, fs_last_error(s_.ctx()));
     }
+    float spawnRadius = 15.0f;  // Part:91
+    int spawnCount = 10;        // Part:84
+    // addParticles(at:count:windowSize:), Part:186-231, on the device; `seed` stands in for the system RNG (:203-212)
+    void addParticles(float2 at, int count, unsigned seed)
+    {
+        int rc = fs_particles_spawn(s_.ctx(), at.x, at.y, count, spawnRadius, seed);
+        if (rc) throw Error(rc, fs_last_error(s_.ctx()));
+    }
     void update(float2 windowSize)  // update(fluidSolver:windowSize:), Part:242-304
     {
         fs_particle_params pp{momentum, fluidForce, fluidDecayRate, linkToViscosity ? 1 : 0, s_.viscosity,

@@ -39,23 +39,12 @@ public final class ParticleSystem {
         return a
     }
 
-    /// addParticles(at:count:windowSize:), :186-231: spawn around a point, live tracers kept, oldest dropped at the cap.
-    public func addParticles(atX x: Float, y: Float, count: Int? = nil, capacity: Int) throws {
+    /// addParticles(at:count:windowSize:), :186-231, on the device (fs_particles_spawn): live tracers kept in age order,
+    /// oldest dropped at the cap (:196-199).  The seed stands in for Float.random's system RNG (:203-212).
+    public func addParticles(atX x: Float, y: Float, count: Int? = nil) throws {
         guard isEnabled else { return }
-        var cur = particleCount > 0 ? try getParticles() : [[Float]](repeating: [], count: 7)
-        let alive = cur[4].indices.filter { cur[4][$0] != 0 }
-        cur = cur.map { plane in alive.map { plane[$0] } }
-        for _ in 0..<(count ?? spawnCount) {
-            cur[0].append(x + Float.random(in: -spawnRadius...spawnRadius, using: &rng))   // :202-205
-            cur[1].append(y + Float.random(in: -spawnRadius...spawnRadius, using: &rng))
-            cur[2].append(0); cur[3].append(0)
-            cur[4].append(Float.random(in: 0.3...1.0, using: &rng))                        // :211
-            cur[5].append(Float.random(in: 0.1...1.0, using: &rng))                        // :212
-            cur[6].append(0)
-        }
-        let drop = max(0, cur[0].count - capacity)                                         // :196-199
-        cur = cur.map { Array($0.dropFirst(drop)) }
-        try setParticles(px: cur[0], py: cur[1], vx: cur[2], vy: cur[3], life: cur[4], mass: cur[5], age: cur[6])
+        let seed = UInt32.random(in: 1...UInt32.max, using: &rng)
+        try check(fs_particles_spawn(solver.context, x, y, count ?? spawnCount, spawnRadius, seed))
     }
 
     /// update(fluidSolver:windowSize:), :242-304, on the device, sampling the real velocity field.

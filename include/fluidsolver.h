@@ -330,6 +330,14 @@ int fs_particles_get(fs_ctx *ctx, long n, float *px, float *py, float *vx, float
 int fs_default_particle_params(fs_particle_params *pp, float windowW, float windowH);
 int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
 long fs_particles_count(fs_ctx *ctx);
+/* ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on the device: `count` new tracers at (x, y) + U(-radius,
+ * radius)^2 in window units (:202-205, spawnRadius :91), zero velocity (:208), life = alpha ~ U(0.3, 1) (:211, :221), mass ~
+ * U(0.1, 1) (:212), age 0.  The reference's array is the live tracers in age order, appended to with removeFirst() at
+ * maxParticles (:196-199): afterwards the context holds the last `max_particles` of (live tracers + new ones), in that order,
+ * and no dead slots.  The reference draws from the system RNG; here tracer j of the call draws offset x, offset y, alpha, mass
+ * from an xorshift32 stream seeded seed ^ (j + 1) * 0x9E3779B9, so a host that wants fresh tracers passes a fresh seed per
+ * call.  Blocking, like fs_particles_set; single GPU. */
+int fs_particles_spawn(fs_ctx *ctx, float x, float y, long count, float radius, unsigned seed);
 /* (Re)allocate room for `capacity` tracers on this context; existing tracers are dropped.  On a slab this is
  * the only way to get tracer storage (capacity is per rank: leave headroom for tracers that migrate in). */
 /* Line vertices of the context's tracers (fs_k_particle_lines) into host arrays of 4 n and n floats. Blocking. */

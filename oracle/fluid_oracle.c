@@ -467,6 +467,44 @@ unsigned fo_xorshift32(unsigned *state)
 }
 
 /* U[lo,hi): 24 random bits -> [0,1) exactly representable, then affine in fp32. */
+static float spawn_draw(unsigned *st, float lo, float hi)
+{
+    float r01 = (float)(fo_xorshift32(st) >> 8) * (1.0f / 16777216.0f);
+    return lo + (hi - lo) * r01;
+}
+
+/* Part:186-231, see fluid_oracle.h */
+void fo_particles_spawn(long cap, long *n, float *px, float *py, float *vx, float *vy, float *life, float *mass, float *age,
+                        float x, float y, long count, float radius, unsigned seed)
+{
+    float *a[7] = {px, py, vx, vy, life, mass, age};
+    long m = 0;
+    for (long i = 0; i < *n; ++i) {            /* the reference's array holds no dead tracers (Part:294-296) */
+        if (life[i] == 0.0f) continue;
+        for (int k = 0; k < 7; ++k) a[k][m] = a[k][i];
+        ++m;
+    }
+    for (long j = 0; j < count; ++j) {         /* Part:195 */
+        if (cap <= 0) break;
+        if (m >= cap) {                        /* Part:196-199 removeFirst() */
+            for (int k = 0; k < 7; ++k)
+                for (long i = 1; i < m; ++i) a[k][i - 1] = a[k][i];
+            --m;
+        }
+        unsigned st = seed ^ ((unsigned)(j + 1) * 0x9E3779B9u);
+        if (!st) st = 1u;
+        const float ox = spawn_draw(&st, -radius, radius);       /* Part:202-205 */
+        const float oy = spawn_draw(&st, -radius, radius);
+        const float alpha = spawn_draw(&st, 0.3f, 1.0f);         /* Part:211 */
+        const float ms = spawn_draw(&st, 0.1f, 1.0f);            /* Part:212 */
+        px[m] = x + ox; py[m] = y + oy;                          /* Part:218 */
+        vx[m] = 0.0f; vy[m] = 0.0f;                              /* Part:208 */
+        life[m] = alpha; mass[m] = ms; age[m] = 0.0f;            /* Part:221-223 */
+        ++m;
+    }
+    *n = m;
+}
+
 void fo_fill_uniform(float *dst, long n, float lo, float hi, unsigned seed)
 {
     unsigned st = seed ? seed : 1u;

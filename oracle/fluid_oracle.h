@@ -107,6 +107,16 @@ void fo_particle_lines(long n, const float *px, const float *py, const float *vx
                        const float *life, float viewW, float viewH, float particleScale,
                        float *out_xy, float *out_alpha);
 
+/* ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on SoA arrays that may hold dead slots (life == 0; the
+ * reference removes a tracer when it dies, Part:296, so its array is the live tracers in age order).  *n slots are in
+ * use, `cap` = maxParticles (Part:53).  Literally: drop the dead slots (order kept), then for each of `count` new
+ * tracers: if the array is full remove its FIRST element (:196-199), append {pos + U(-r, r)^2, vel 0, life = alpha ~
+ * U(0.3, 1), mass ~ U(0.1, 1), age 0} (:202-226).  The reference draws from the system RNG; here new tracer j draws its
+ * four numbers, in the order offset x, offset y, alpha, mass, from an xorshift32 stream of its own seeded with
+ * seed ^ (j + 1) * 0x9E3779B9 (0 -> 1), each as lo + (hi - lo) * ((x >> 8) * 2^-24) in fp32.  Returns the new *n. */
+void fo_particles_spawn(long cap, long *n, float *px, float *py, float *vx, float *vy, float *life, float *mass, float *age,
+                        float x, float y, long count, float radius, unsigned seed);
+
 /* xorshift32 harness RNG (SURVEY 8(d) config 3 / Jacobi micro-benchmark). */
 unsigned fo_xorshift32(unsigned *state);
 void fo_fill_uniform(float *dst, long n, float lo, float hi, unsigned seed);

@@ -85,6 +85,8 @@ class Oracle:
         L.fo_field.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.fo_field.restype = FP
         L.fo_particles_update.argtypes = [G, FP, FP, C.POINTER(ParticleParams), C.c_long] + [FP] * 7
+        L.fo_particles_spawn.argtypes = [C.c_long, C.POINTER(C.c_long)] + [FP] * 7 + [f, f, C.c_long, f, C.c_uint]
+        L.fo_particles_spawn.restype = None
         L.fo_particle_lines.argtypes = [C.c_long] + [FP] * 5 + [f] * 3 + [FP] * 2
         L.fo_fill_uniform.argtypes = [FP, C.c_long, f, f, C.c_uint]
         L.fo_omp_threads.restype = C.c_int
@@ -139,6 +141,13 @@ class Oracle:
         xy, alpha = np.empty((n, 4), np.float32), np.empty(n, np.float32)
         self.lib.fo_particle_lines(n, _p(px), _p(py), _p(vx), _p(vy), _p(life), view[0], view[1], scale, _p(xy), _p(alpha))
         return xy, alpha
+
+    def particles_spawn(self, cap, arrs, x, y, count, radius, seed):
+        """arrs: seven arrays of the slots in use; returns the seven arrays after the spawn (dead slots dropped)."""
+        n = C.c_long(len(arrs[0]))
+        buf = [np.concatenate([np.asarray(a, np.float32), np.zeros(max(0, cap - len(a)), np.float32)]) for a in arrs]
+        self.lib.fo_particles_spawn(cap, C.byref(n), *[_p(b) for b in buf], x, y, count, radius, seed)
+        return [b[:n.value].copy() for b in buf]
 
     def particles_update(self, g, u, v, pp, arrs):
         n = arrs[0].shape[0]

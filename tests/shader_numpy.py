@@ -211,3 +211,89 @@ def particles_update(u, v, arrs, momentum, fluidForce, fluidDecayRate, linkToVis
     alive = life != 0
     return [np.where(alive, new, old).astype(F) for new, old in
             zip((npx, npy, nvx, nvy, nl, mass, nage), (px, py, vx, vy, life, mass, age))]
+
+
+def _xorshift32(x):
+    x ^= (x << np.uint32(13)) & np.uint32(0xFFFFFFFF)
+    x ^= x >> np.uint32(17)
+    x ^= (x << np.uint32(5)) & np.uint32(0xFFFFFFFF)
+    return x
+
+
+def particles_spawn(cap, arrs, x, y, count, radius, seed):
+    """ParticleSystem.addParticles, fluidSolver/Models/ParticleSystem.swift:186-231, whole-array: the reference's array is
+    the live tracers in age order (dead ones are removed when they die, :294-296); `count` appends with removeFirst() at
+    the cap (:196-199) leave the last `cap` elements of (live + new).  New tracer j: offsets U(-r, r)^2 (:202-205), zero
+    velocity (:208), life = alpha ~ U(0.3, 1) (:211, :221), mass ~ U(0.1, 1) (:212), age 0 (:223); the four draws come from
+    an xorshift32 stream seeded seed ^ (j + 1) * 0x9E3779B9 (the harness's stand-in for Float.random)."""
+    live = arrs[4] != 0
+    old = [np.asarray(a, F)[live] for a in arrs]
+    j = np.arange(1, count + 1, dtype=np.uint64)
+    st = (np.uint32(seed) ^ ((j * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)).astype(np.uint32)
+    st = np.where(st == 0, np.uint32(1), st)
+    draws = []
+    with np.errstate(over="ignore"):
+        for lo, hi in ((-radius, radius), (-radius, radius), (0.3, 1.0), (0.1, 1.0)):
+            st = _xorshift32(st)
+            r01 = (st >> np.uint32(8)).astype(F) * F(1.0 / 16777216.0)
+            draws.append(F(lo) + (F(hi) - F(lo)) * r01)
+    z = np.zeros(count, F)
+    new = [F(x) + draws[0], F(y) + draws[1], z, z, draws[2], draws[3], z]
+    if cap <= 0:
+        return [a[:0] for a in old]
+    return [np.concatenate([a, b]).astype(F)[-cap:] for a, b in zip(old, new)]
+
+
+# ---- input front-end: ColorPalette.getColor(for:) and FluidSolver.addForce(at:windowSize:) ----------------------------
+SWIFT_FLOAT_PI = np.frombuffer(np.uint32(0x40490FDA).tobytes(), dtype=np.float32)[0]   # Float.pi: pi rounded toward zero
+
+
+def _sinf(x):
+    return np.sin(x.astype(np.float64)).astype(F)
+
+
+def _hsb(h):
+    """hsbToRgb(h, 1, 1), fluidSolver/Models/ColorPalette.swift:107-128, for an array of hues."""
+    c = F(1.0) * F(1.0)
+    x = c * (F(1) - np.abs(np.fmod(h * F(6), F(2)) - F(1)))
+    m = F(1.0) - c
+    z = np.zeros_like(h)
+    cc = np.full_like(h, c)
+    sixth = [F(k) / F(6.0) for k in range(1, 6)]
+    sector = sum((h >= t).astype(np.int64) for t in sixth)
+    table = [(cc, x, z), (x, cc, z), (z, cc, x), (z, x, cc), (x, z, cc), (cc, z, x)]
+    rgb = [np.choose(sector, [t[k] for t in table]) + m for k in range(3)]
+    return np.stack(rgb + [np.ones_like(h)], axis=-1).astype(F)
+
+
+def palette_colors(name, frames):
+    """getColor(for: Float(frameNumber % 360) / 360.0), ColorPalette.swift:40-95 with the phase of FluidSolver.swift:422-423,
+    for an array of frame numbers; whole-array, written from the Swift text (Float arithmetic, Float.pi)."""
+    t = (np.asarray(frames) % 360).astype(F) / F(360.0)
+    pi = SWIFT_FLOAT_PI
+    one = np.ones_like(t)
+    ph = t * F(2) * pi
+    if name == "Rainbow":
+        return _hsb(t)
+    if name == "Neon":
+        return _hsb(np.fmod(t * F(1.5), F(1.0)))
+    if name == "Fire":
+        return np.stack([one, np.minimum(F(1.0), t * F(2)), np.maximum(F(0), (t - F(0.5)) * F(2)), one], -1).astype(F)
+    if name == "Greyscale":
+        b = F(0.5) + F(0.5) * _sinf(ph)
+        return np.stack([b, b, b, one], -1).astype(F)
+    coef = {"Ocean": ((0.2, 0.3, None), (0.5, 0.4, pi / F(3)), (0.8, 0.2, None)),
+            "Plasma": ((0.5, 0.5, None), (0.3, 0.5, F(2) * pi / F(3)), (0.8, 0.2, F(4) * pi / F(3))),
+            "Sunset": ((0.9, 0.1, None), (0.3, 0.4, pi / F(2)), (0.4, 0.6, pi)),
+            "Vapor": ((0.7, 0.3, None), (0.3, 0.3, pi / F(2)), (0.9, 0.1, pi))}[name]
+    ch = [F(a) + F(b) * _sinf(ph if sh is None else ph + sh) for a, b, sh in coef]
+    return np.stack(ch + [one], -1).astype(F)
+
+
+def add_force_inputs(at, window, grid, previous, force_multiplier, color_multiplier, palette, frame):
+    """What FluidSolver.addForce(at:windowSize:) hands to applyForce (FluidSolver.swift:409-428): grid position, force from
+    the previous touch (zero on the first), palette colour times colorMultiplier.  Returns (pos, force, rgba)."""
+    pos = np.array([F(at[0] / window[0]) * F(grid[0]), F(at[1] / window[1]) * F(grid[1])], F)     # :410-413
+    force = np.zeros(2, F) if previous is None else (pos - previous) * F(force_multiplier)      # :415-419
+    color = palette_colors(palette, np.array([frame]))[0] * F(color_multiplier)                   # :422-424
+    return pos, force, color

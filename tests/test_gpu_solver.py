@@ -326,8 +326,18 @@ def test_host_api_add_force_and_reset():
     s.addForce((100.0, 100.0), (400.0, 400.0), time=0.0)       # first touch: zero force, dye only
     assert not s.read_field(L.FIELD_VELOCITY).any() and s.read_field(L.FIELD_DENSITY)[0].max() == F(50.0)
     s.addForce((110.0, 100.0), (400.0, 400.0), time=0.0)       # 10 px -> 3.2 cells -> force 76.8
-    u = s.read_field(L.FIELD_VELOCITY)[0]
-    assert u.max() > 0 and u[32, 35] == F(76.8 * 0.5) * F(1.0) or u.max() > 30
+    # exact: addForce(at:windowSize:) restated from FluidSolver.swift:409-428 (tests/shader_numpy.py) into the oracle's splat
+    import shader_numpy as S
+    from oracle_binding import DENSITY, VELOCITY, Oracle
+    o = Oracle().solver(128, 128)
+    prev = None
+    for at in ((100.0, 100.0), (110.0, 100.0)):
+        pos, force, col = S.add_force_inputs(at, (400.0, 400.0), (128, 128), prev, s.forceMultiplier, s.colorMultiplier, "Rainbow", 0)
+        o.add_force(pos, force, col[:3], s.forceRadius, s.deltaTime)
+        prev = pos
+    assert force[0] == F(76.8) or abs(float(force[0]) - 76.8) < 1e-4
+    assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY)) and s.read_field(L.FIELD_VELOCITY)[0].max() > 30
+    assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY))
     s.endInteraction()
     s.applyPreset("Turbulent")
     assert s.solverIterations == 10 and s.vorticityStrength == 25.0
@@ -537,3 +547,84 @@ def test_frames_match_second_restatement(W, H, params, frames):
     assert np.array_equal(s.read_field(L.FIELD_PRESSURE)[0], r.p)
     assert float(np.abs(np.stack(r.vel)).max()) > 0 and float(np.stack(r.dens).max()) > 0
     s.close()
+
+
+@pytest.mark.gpu
+def test_spawn_on_device_matches_oracle(oracle):
+    # fs_particles_spawn (ParticleSystem.addParticles, ParticleSystem.swift:186-231) through the context: interleaved with
+    # tracer updates that kill some tracers, up to and beyond the cap, against the oracle's sequential restatement
+    import ctypes as C
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    from oracle_binding import ParticleParams as OPP, full_grid, VELOCITY
+    lib = L.load()
+    W, H, cap = 160, 120, 5000
+    s = FluidSolver(W, H, max_particles=cap)
+    ps = ParticleSystem(s)
+    ps.momentum = 0.9
+    rng = np.random.default_rng(5)
+    vel = rng.uniform(-60, 60, (2, H, W)).astype(np.float32)      # fast flow: tracers leave the window and die (:282-288)
+    s.write_field(L.FIELD_VELOCITY, vel)
+    exp = [np.zeros(0, np.float32) for _ in range(7)]
+    try:
+        for step, (x, y, count, seed) in enumerate([(80.0, 60.0, 700, 11), (10.0, 5.0, 1500, 12), (150.0, 110.0, 2500, 13),
+                                                    (80.0, 60.0, 0, 14), (5.0, 115.0, 1200, 15), (80.0, 60.0, 6000, 16),
+                                                    (20.0, 20.0, 1, 17)]):
+            L.check(lib.fs_particles_spawn(s.ctx, x, y, count, 15.0, seed), s.ctx)
+            exp = oracle.particles_spawn(cap, exp, x, y, count, 15.0, seed)
+            assert ps.particleCount == len(exp[0])
+            got = ps.get_arrays()
+            assert all(np.array_equal(a, b) for a, b in zip(got, exp)), step
+            for _ in range(4):
+                ps.update(s, (W, H))
+                if len(exp[0]):
+                    oracle.particles_update(full_grid(W, H), vel[0], vel[1], OPP(0.9, 0.6, 3.0, 1, s.viscosity, W, H), exp)
+            got = ps.get_arrays()
+            assert all(np.array_equal(a, b) for a, b in zip(got, exp)), step
+        assert (exp[4] == 0).any() and (exp[4] != 0).any()          # the run did see dead slots and live tracers
+        # a large population: more blocks than one scan segment holds
+        big = FluidSolver(W, H, max_particles=300000)
+        pb = ParticleSystem(big)
+        e2 = [np.zeros(0, np.float32) for _ in range(7)]
+        for x, count, seed in ((40.0, 200000, 21), (90.0, 150000, 22)):
+            L.check(lib.fs_particles_spawn(big.ctx, x, 60.0, count, 15.0, seed), big.ctx)
+            e2 = oracle.particles_spawn(300000, e2, x, 60.0, count, 15.0, seed)
+            assert all(np.array_equal(a, b) for a, b in zip(pb.get_arrays(), e2))
+        big.close()
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_config3_full_size_matches_oracle(oracle_omp):
+    # BASELINE config 3 as bench.py runs it: 3072^2, N = 40, 1,048,576 tracers seeded as SURVEY 8(d) (xorshift32
+    # 0x9E3779B9), the tracer update as the last node of the frame (FS_OPT_WITH_PARTICLES; frame 3 is a graph replay):
+    # fields and all seven tracer arrays against the oracle
+    import ctypes as C
+    import bench
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, VELOCITY, ParticleParams as OPP, Params, full_grid
+    W = H = 3072
+    wl = bench.WORKLOADS["config3"]
+    s, ps = bench.make_single(W, H, wl["params"], wl["particles"])
+    try:
+        exp = ps.get_arrays()
+        assert len(exp[0]) == 1 << 20 and (exp[4] != 0).all()
+        o = oracle_omp.solver(W, H)
+        p = Params(*wl["params"])
+        for f in range(4):
+            bench.frame_single(s, ps, f, W, H)
+            pos, force, col = splat(W, H, f)
+            o.add_force(pos, force, col, 5.0, p.deltaTime)
+            o.update(p)
+            vel = o.field(VELOCITY)
+            oracle_omp.particles_update(full_grid(W, H), vel[0], vel[1], OPP(0.5, 0.6, 3.0, 1, wl["params"][0], W, H), exp)
+        s.sync()
+        assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY))
+        assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY))
+        got = ps.get_arrays()
+        for name, a, b in zip("px py vx vy life mass age".split(), got, exp):
+            assert np.array_equal(a, b), name
+        assert (got[2] != 0).any()   # some tracers did pick up fluid velocity
+    finally:
+        s.close()

@@ -395,3 +395,25 @@ def test_oracle_is_clean_under_asan_and_ubsan():
     out = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "sanitize_check ok" in out.stdout
+
+
+def test_spawn_ranges_order_and_cap(oracle):
+    # ParticleSystem.swift:186-231: new tracers at pos + U(-r, r)^2 with zero velocity, life = alpha in [0.3, 1], mass in
+    # [0.1, 1], age 0 (:202-223); live tracers keep their order, dead ones are gone; at the cap the OLDEST go first (:196-199)
+    F = np.float32
+    old = [np.arange(10, dtype=F) + 100 * k for k in range(7)]
+    old[4] = np.array([1, 0, 1, 1, 0, 1, 1, 1, 0, 1], F)          # slots 1, 4, 8 dead
+    out = oracle.particles_spawn(12, old, 400.0, 300.0, 4, 15.0, 42)
+    live = [0, 2, 3, 5, 6, 7, 9]
+    assert len(out[0]) == 11
+    for k in (0, 1, 2, 3, 5, 6):
+        assert np.array_equal(out[k][:7], old[k][live])
+    new = [a[7:] for a in out]
+    assert (np.abs(new[0] - 400.0) <= 15.0).all() and (np.abs(new[1] - 300.0) <= 15.0).all()
+    assert (new[2] == 0).all() and (new[3] == 0).all() and (new[6] == 0).all()
+    assert ((new[4] >= F(0.3)) & (new[4] <= 1.0)).all() and ((new[5] >= F(0.1)) & (new[5] <= 1.0)).all()
+    assert len(set(new[0].tolist())) == 4                          # every tracer draws from a stream of its own
+    # three more than fit: the three oldest live tracers (slots 0, 2, 3) are pushed out
+    out2 = oracle.particles_spawn(12, old, 400.0, 300.0, 8, 15.0, 42)
+    assert len(out2[0]) == 12 and np.array_equal(out2[0][:4], old[0][[5, 6, 7, 9]])
+    assert np.array_equal(out2[0][4:8], new[0])                    # tracer j of a call does not depend on the count

@@ -170,3 +170,35 @@ def test_golden_vectors_equal_the_second_restatement(name):
             assert same(gold["prs_%d" % (f + 1)][0], s.p), (name, f + 1)
             seen += 1
     assert seen == len(c["save_at"])
+
+
+@pytest.mark.parametrize("cap,n,count", [(100, 60, 30), (100, 90, 30), (50, 50, 10), (40, 30, 100), (10, 0, 3), (64, 64, 0),
+                                         (1000, 999, 2), (7, 7, 7)])
+def test_spawn_agrees_bit_for_bit(oracle, cap, n, count):
+    F = np.float32
+    # ParticleSystem.addParticles (ParticleSystem.swift:186-231): the sequential C restatement (remove dead, then per new
+    # tracer removeFirst() at the cap + append) against the whole-array numpy one (last `cap` of live + new)
+    rng = np.random.default_rng(cap * 1000 + n)
+    arrs = [rng.uniform(0, 100, n).astype(F) for _ in range(7)]
+    arrs[4][::3] = 0
+    for seed in (1234, 0, 0x9E3779B9, 0xFFFFFFFF):
+        a = oracle.particles_spawn(cap, arrs, 50.0, 60.0, count, 15.0, seed)
+        b = S.particles_spawn(cap, arrs, 50.0, 60.0, count, 15.0, seed)
+        assert len(a[0]) == min(cap, int((arrs[4] != 0).sum()) + count)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_all_palettes_all_phases_agree():
+    # ColorPalette.getColor(for:) (ColorPalette.swift:40-128) at the 360 phases addForce can produce (FluidSolver.swift:
+    # 422-423): the host mirror's scalar restatement against the whole-array one of this directory, 8 x 360 colours
+    from fluidsolver_amd.presets import PALETTES, palette_color
+    frames = np.arange(360)
+    assert len(PALETTES) == 8
+    for name in PALETTES:
+        whole = S.palette_colors(name, frames)
+        each = np.stack([palette_color(name, np.float32(k) / np.float32(360.0)) for k in frames])
+        assert whole.shape == (360, 4) and np.array_equal(whole, each), name
+        assert (whole[:, 3] == 1).all() and whole[:, :3].max() <= 1.0 + 1e-6   # (Ocean's red dips to -0.1: 0.2 + 0.3 sin, :49)
+    # known answers: rainbow at phase 0 is pure red, at 120/360 pure green; fire starts red and ends yellow-white
+    assert S.palette_colors("Rainbow", [0])[0].tolist() == [1, 0, 0, 1] and S.palette_colors("Rainbow", [120])[0].tolist() == [0, 1, 0, 1]
+    assert S.palette_colors("Fire", [0])[0].tolist() == [1, 0, 0, 1]
