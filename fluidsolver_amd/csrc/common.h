@@ -15,6 +15,25 @@ struct GK {
 
 inline GK make_gk(const fs_grid *g) { return GK{g->width, g->height, g->pitch, g->y0, g->rows}; }
 
+// Tuning of the two Jacobi loops.  One process-wide default (fs_config_set: what the per-kernel entry points fs_k_*_n use and
+// what a new context starts from) and one copy per context (fs_set_option), so two contexts never change each other's.
+struct JacobiTuning {
+    int depth[2];      // sweeps fused per launch: [0] pressure, [1] diffuse
+    int variant[2];    // register-tile shape, see launch_block
+    int stagger, stagger_mode;
+};
+JacobiTuning &default_tuning();
+int tuning_set(JacobiTuning &t, int key, int value);   // key = FS_OPT_*; FS_ERR_INVALID for an unknown key or a bad value
+int tuning_get(const JacobiTuning &t, int key);
+int jacobi_launch_count(const JacobiTuning &t, int op, int n);
+// fs_k_pressureSolve_n / fs_k_project_n_cfl / fs_k_diffuse_n with an explicit tuning (the context's)
+int pressure_n(const JacobiTuning &t, const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero, int *result_in_b,
+               void *stream);
+int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
+                  int *result_in_b, void *stream);
+int diffuse_n(const JacobiTuning &t, const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
+              float deltaTime, int n, int *result_in_b, void *stream);
+
 void set_error(const char *fmt, ...);
 const char *get_error();
 int check_grid(const fs_grid *g);

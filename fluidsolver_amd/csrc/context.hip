@@ -11,12 +11,6 @@
 
 namespace fs {
 
-int config_set_block_depth(int op, int v);
-int config_get_block_depth(int op);
-int config_set_tile_variant(int op, int v);
-int config_get_tile_variant(int op);
-int config_set_stagger(int ticks, int mode);
-int config_get_stagger();
 
 static thread_local char tl_error[512] = "";
 
@@ -117,9 +111,9 @@ static int st_sweeps(fs_ctx *c, int fi, int n, bool pressure, bool p_is_zero)
     Field &F = c->f[fi];
     int in_b = 0, rc;
     if (pressure)
-        rc = fs_k_pressureSolve_n(&c->grid, c->f[F_DIV].p(), F.p(), F.t(), n, p_is_zero ? 1 : 0, &in_b, c->stream);  // Solver:533-541
+        rc = fs::pressure_n(c->tuning, &c->grid, c->f[F_DIV].p(), F.p(), F.t(), n, p_is_zero ? 1 : 0, &in_b, c->stream);  // Solver:533-541
     else
-        rc = fs_k_diffuse_n(&c->grid, F.p(), F.t(), F.np, c->plane, fi == F_VEL ? c->params.viscosity : c->params.diffusion,
+        rc = fs::diffuse_n(c->tuning, &c->grid, F.p(), F.t(), F.np, c->plane, fi == F_VEL ? c->params.viscosity : c->params.diffusion,
                             c->params.deltaTime, n, &in_b, c->stream);                 // Solver:506-517, :563-573
     if (!rc && in_b) F.cur ^= 1;
     return rc;
@@ -184,8 +178,9 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
 {
     if (!out) { fs::set_error("fs_create: out is NULL"); return FS_ERR_INVALID; }
     *out = nullptr;
-    if (width < 1 || height < 1 || width > (1 << 22) || height > (1 << 22) || max_particles < 0) {
-        fs::set_error("fs_create: bad size %dx%d / %ld particles", width, height, max_particles);
+    // height: the streaming passes put ceil(rows / 4), padded to a multiple of 64, into gridDim.y (at most 65535)
+    if (width < 1 || height < 1 || width > (1 << 22) || height > 261888 || max_particles < 0) {
+        fs::set_error("fs_create: bad size %dx%d / %ld particles (width <= 4194304, height <= 261888)", width, height, max_particles);
         return FS_ERR_INVALID;
     }
     const int own_min = height / world;
@@ -207,6 +202,7 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
     c->plane = (size_t)c->pitch * (size_t)(c->b1 - c->b0);
     c->grid = fs::grid_of(c, 0);
     c->f[F_VEL].np = 2; c->f[F_DYE].np = 3;
+    c->tuning = fs::default_tuning();
     fs_default_params(&c->params);
     fs_default_particle_params(&c->pparams, (float)width, (float)height);
     c->max_particles = max_particles;
@@ -393,17 +389,16 @@ int fs_set_option(fs_ctx *c, int option, int value)
     CTX(c);
     switch (option) {
     case FS_OPT_USE_GRAPH: c->use_graph = value ? 1 : 0; break;
-    case FS_OPT_BLOCK_DEPTH:
-        if (fs::config_set_block_depth(-1, value)) { fs::set_error("block depth %d out of range 1..48", value); return ctx_fail(c, FS_ERR_INVALID); }
+    case FS_OPT_BLOCK_DEPTH: case FS_OPT_BLOCK_DEPTH_PRESSURE: case FS_OPT_BLOCK_DEPTH_DIFFUSE:
+    case FS_OPT_TILE_VARIANT: case FS_OPT_TILE_VARIANT_DIFFUSE: case FS_OPT_STAGGER: case FS_OPT_STAGGER_MODE:
+        // this context's own copy: another context in the process keeps its tuning (fs_config_set changes the default)
+        if (fs::tuning_set(c->tuning, option, value)) { fs::set_error("option %d: value %d out of range", option, value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
     case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
     case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 4) ? value : 1; break;
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
     case FS_OPT_SPLIT_PLANES: c->split_planes = value ? 1 : 0; break;
-    case FS_OPT_TILE_VARIANT:
-        if (fs::config_set_tile_variant(-1, value)) { fs::set_error("tile variant %d out of range", value); return ctx_fail(c, FS_ERR_INVALID); }
-        break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     drop_graphs(c);
@@ -622,8 +617,8 @@ int fs_particles_reserve(fs_ctx *c, long capacity)
         const size_t w = (size_t)c->world;
         TRYHIP(c, hipMalloc((void **)&c->tr_counts_dev, w * sizeof(int)));
         TRYHIP(c, hipHostMalloc((void **)&c->tr_counts_host, w * sizeof(int), hipHostMallocDefault));
-        TRYHIP(c, hipMalloc((void **)&c->tr_matrix_dev, w * w * sizeof(float)));
-        TRYHIP(c, hipHostMalloc((void **)&c->tr_matrix_host, w * w * sizeof(float), hipHostMallocDefault));
+        TRYHIP(c, hipMalloc((void **)&c->tr_matrix_dev, w * w * sizeof(int)));
+        TRYHIP(c, hipHostMalloc((void **)&c->tr_matrix_host, w * w * sizeof(int), hipHostMallocDefault));
     }
     c->max_particles = capacity;
     return FS_OK;
@@ -782,25 +777,7 @@ int fs_harness_fill_uniform(float *dst, long n, float lo, float hi, unsigned see
     return FS_OK;
 }
 
-int fs_config_set(int key, int value)
-{
-    if (key == FS_OPT_BLOCK_DEPTH) return fs::config_set_block_depth(-1, value);
-    if (key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_set_block_depth(0, value);
-    if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_set_block_depth(1, value);
-    if (key == FS_OPT_TILE_VARIANT) return fs::config_set_tile_variant(-1, value);
-    if (key == FS_OPT_TILE_VARIANT_DIFFUSE) return fs::config_set_tile_variant(1, value);
-    if (key == FS_OPT_STAGGER) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(value, -1);
-    if (key == FS_OPT_STAGGER_MODE) return value < 0 ? FS_ERR_INVALID : fs::config_set_stagger(-1, value);
-    return FS_ERR_INVALID;
-}
-int fs_config_get(int key)
-{
-    if (key == FS_OPT_BLOCK_DEPTH || key == FS_OPT_BLOCK_DEPTH_PRESSURE) return fs::config_get_block_depth(0);
-    if (key == FS_OPT_BLOCK_DEPTH_DIFFUSE) return fs::config_get_block_depth(1);
-    if (key == FS_OPT_TILE_VARIANT) return fs::config_get_tile_variant(0);
-    if (key == FS_OPT_TILE_VARIANT_DIFFUSE) return fs::config_get_tile_variant(1);
-    if (key == FS_OPT_STAGGER) return fs::config_get_stagger();
-    return FS_ERR_INVALID;
-}
+int fs_config_set(int key, int value) { return fs::tuning_set(fs::default_tuning(), key, value); }
+int fs_config_get(int key) { return fs::tuning_get(fs::default_tuning(), key); }
 
 }  // extern "C"

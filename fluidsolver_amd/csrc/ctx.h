@@ -110,6 +110,7 @@ struct fs_ctx {
     int stable_frames = 0;              // frames since the parameters / options last changed (graphs are recorded once they settle)
     int with_particles = 0;
     int fuse = 1;
+    fs::JacobiTuning tuning{};          // block depths / tile shapes of this context's Jacobi loops (starts from the process default)
     // independent planes of a diffuse loop as two concurrent chains (second stream, fork/join by event)
     int split_planes = 1;
     hipStream_t stream2 = nullptr;
@@ -133,8 +134,8 @@ struct fs_ctx {
     float *outbox[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *tr_counts_dev = nullptr;       // `world` ints: counts, then cursors
     int *tr_counts_host = nullptr;      // pinned, `world` ints: how many of my tracers go to each rank
-    float *tr_matrix_dev = nullptr;     // RCCL: world x world counts as floats, summed over ranks
-    float *tr_matrix_host = nullptr;    // pinned
+    int *tr_matrix_dev = nullptr;       // RCCL: world x world counts, summed over ranks (ncclInt32)
+    int *tr_matrix_host = nullptr;      // pinned
     std::vector<long> tr_send_off, tr_recv_cnt;
     long stat_migrated = 0;
     int *spawn_sums = nullptr;          // fs_particles_spawn: live counts per block of 256 slots, then their scan (blocks + 1 ints)

@@ -385,14 +385,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     }
 }
 
-// tuning knobs (process-wide; see fs_config_set)
+// tuning knobs (JacobiTuning, common.h: a process-wide default and a copy per context)
 // From the 3072^2 sweeps in profiles/r01_tune_jacobi*.log.  Depths: the pressure sweep is cheap per cell, so
 // fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
 // Tile: 4 rows per lane x 16 waves (64 VGPRs, 8 waves per SIMD).  The sweeps are bound by VALU issue and by
 // the per-sweep barrier, and twice the waves hide both better than the larger register tiles do.
-static int g_block_depth[2] = {10, 8};   // [OP_PRESSURE], [OP_DIFFUSE]
-static int g_tile_variant[2] = {4, 4};   // [op]: index into the (R rows per lane, NW waves) table below
-static int g_stagger = 0, g_stagger_mode = 0;
+static JacobiTuning g_tuning = {{10, 8}, {4, 4}, 0, 0};
+JacobiTuning &default_tuning() { return g_tuning; }
 
 template <int OP, int R, int NW, int MINW>
 static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, hipStream_t stream)
@@ -414,7 +413,7 @@ static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, h
 }
 
 template <int OP>
-static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
+static int launch_block(const JacobiTuning &tn, const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
                         int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream,
                         const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr, float *cfl = nullptr)
 {
@@ -438,11 +437,11 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
     A.a = a;
     A.den = den;
     A.rden = 1.0 / (double)den;
-    A.stagger = g_stagger;
-    A.stagger_mode = g_stagger_mode;
+    A.stagger = tn.stagger;
+    A.stagger_mode = tn.stagger_mode;
     // p in, p out and div of the rows in play, against ~3/4 of the 256 MiB Infinity Cache
     A.xcd_chunked = OP == OP_PRESSURE && 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) < 192.0 * 1024 * 1024;
-    switch (g_tile_variant[OP]) {
+    switch (tn.variant[OP]) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
     case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
@@ -458,7 +457,7 @@ static int launch_block(const fs_grid *g, int yb, int ye, const float *in, float
 // rem = sweeps still to come, clipped to the domain.
 // gu/gv != nullptr (pressure): the last launch also subtracts the gradient of the final iterate from them
 template <int OP>
-static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
+static int run_sweeps(const JacobiTuning &tn, const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
                       size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
                       float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr,
                       float *cfl = nullptr)
@@ -471,7 +470,7 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
                   g->ye, need_lo, need_hi, g->y0, g->y0 + g->rows);
         return FS_ERR_INVALID;
     }
-    const int maxT = g_block_depth[OP];
+    const int maxT = tn.depth[OP];
     int rem = n;
     float *src = a, *dst = b;
     bool src_zero = a_is_zero;
@@ -487,7 +486,7 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
         // first launch of a projection: the divergence is computed from gu/gv (still untouched: the epilogue only
         // runs in the last launch) and stored to div_out for the launches that follow
         const bool pro = div_prologue && first && !last;
-        int rc = launch_block<OP>(g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
+        int rc = launch_block<OP>(tn, g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
                                   last ? gu : nullptr, last ? gv : nullptr, stream, pro ? gu : nullptr, pro ? gv : nullptr,
                                   pro ? div_out : nullptr, last ? cfl : nullptr);
         if (rc) return rc;
@@ -500,38 +499,54 @@ static int run_sweeps(const fs_grid *g, const float *div, float *a, float *b, bo
 }
 
 // launches run_sweeps makes for n sweeps (the frame planner needs the ping-pong parity ahead of time)
-int jacobi_launch_count(int op, int n)
+int jacobi_launch_count(const JacobiTuning &t, int op, int n)
 {
-    const int maxT = g_block_depth[op == 1 ? 1 : 0];
+    const int maxT = t.depth[op == 1 ? 1 : 0];
     return n <= 0 ? 0 : (n + maxT - 1) / maxT;
 }
 
-int config_set_block_depth(int op, int v)   // op < 0: both loops
+int tuning_set(JacobiTuning &t, int key, int v)
 {
-    if (v < 1 || v > 48 || op > 1) return FS_ERR_INVALID;
-    if (op < 0) g_block_depth[0] = g_block_depth[1] = v;
-    else g_block_depth[op] = v;
-    return FS_OK;
-}
-int config_get_block_depth(int op) { return g_block_depth[op == 1 ? 1 : 0]; }
-int config_set_tile_variant(int op, int v)   // op < 0: both loops
-{
-    if (v < 0 || v > 7 || op > 1) return FS_ERR_INVALID;
-    if (op < 0) g_tile_variant[0] = g_tile_variant[1] = v;
-    else g_tile_variant[op] = v;
-    return FS_OK;
-}
-int config_get_tile_variant(int op) { return g_tile_variant[op == 1 ? 1 : 0]; }
-int config_set_stagger(int ticks, int mode)
-{
+    switch (key) {
+    case FS_OPT_BLOCK_DEPTH:
+    case FS_OPT_BLOCK_DEPTH_PRESSURE:
+    case FS_OPT_BLOCK_DEPTH_DIFFUSE:
+        if (v < 1 || v > 48) return FS_ERR_INVALID;
+        if (key != FS_OPT_BLOCK_DEPTH_DIFFUSE) t.depth[0] = v;
+        if (key != FS_OPT_BLOCK_DEPTH_PRESSURE) t.depth[1] = v;
+        return FS_OK;
+    case FS_OPT_TILE_VARIANT:
+    case FS_OPT_TILE_VARIANT_DIFFUSE:
+        if (v < 0 || v > 7) return FS_ERR_INVALID;
+        if (key == FS_OPT_TILE_VARIANT) t.variant[0] = v;
+        t.variant[1] = v;
+        return FS_OK;
+    case FS_OPT_STAGGER:
+        if (v < 0) return FS_ERR_INVALID;
+        t.stagger = v;
+        return FS_OK;
+    case FS_OPT_STAGGER_MODE:
 #ifndef FS_PROBE
-    if (mode > 3) return FS_ERR_INVALID;   // modes 0..3 choose which workgroups start late; higher bits exist in probe builds only
+        if (v > 3) return FS_ERR_INVALID;   // modes 0..3 choose which workgroups start late; higher bits exist in probe builds only
 #endif
-    if (ticks >= 0) g_stagger = ticks;
-    if (mode >= 0) g_stagger_mode = mode;
-    return FS_OK;
+        if (v < 0) return FS_ERR_INVALID;
+        t.stagger_mode = v;
+        return FS_OK;
+    }
+    return FS_ERR_INVALID;
 }
-int config_get_stagger() { return g_stagger; }
+int tuning_get(const JacobiTuning &t, int key)
+{
+    switch (key) {
+    case FS_OPT_BLOCK_DEPTH:
+    case FS_OPT_BLOCK_DEPTH_PRESSURE: return t.depth[0];
+    case FS_OPT_BLOCK_DEPTH_DIFFUSE: return t.depth[1];
+    case FS_OPT_TILE_VARIANT: return t.variant[0];
+    case FS_OPT_TILE_VARIANT_DIFFUSE: return t.variant[1];
+    case FS_OPT_STAGGER: return t.stagger;
+    }
+    return FS_ERR_INVALID;
+}
 
 // exhaustive check of div_const against the IEEE division: all 2^32 bit patterns of x
 __global__ __launch_bounds__(256) void k_selftest_divide(float den, double rden, unsigned long long *mismatches)
@@ -547,6 +562,71 @@ __global__ __launch_bounds__(256) void k_selftest_divide(float den, double rden,
         bad += same ? 0 : 1;
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+static void diffuse_coeffs(const fs_grid *g, float viscosity, float dt, float *a, float *den)
+{
+    // Shaders:96  a = deltaTime * viscosity * width * height  (uint -> float)
+    *a = ((dt * viscosity) * (float)(unsigned)g->width) * (float)(unsigned)g->height;
+    *den = 1.0f + 4.0f * *a;  // Shaders:103
+}
+
+#define REQUIRE_FS(who, cond, msg)              \
+    do {                                        \
+        if (!(cond)) { set_error("%s: %s", who, msg); return FS_ERR_INVALID; } \
+    } while (0)
+
+int pressure_n(const JacobiTuning &t, const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero, int *result_in_b,
+               void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE_FS("fs_k_pressureSolve_n", div && pa && pb && pa != pb, "bad pointers");
+    REQUIRE_FS("fs_k_pressureSolve_n", n >= 0, "negative sweep count");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb) return FS_OK;
+    if (n == 0) {
+        if (p_is_zero) return fs_k_clear(g, pa, 1, 0, stream);
+        return FS_OK;
+    }
+    return run_sweeps<OP_PRESSURE>(t, g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream);
+}
+
+int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
+                  int *result_in_b, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE_FS("fs_k_project_n", u && v && div && pa && pb && pa != pb, "bad pointers");
+    REQUIRE_FS("fs_k_project_n", n >= 1, "needs at least one sweep");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb) return FS_OK;
+    if (jacobi_launch_count(t, OP_PRESSURE, n) < 2) {
+        // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads):
+        // the divergence of the rows the sweeps read stays a separate pass
+        fs_grid gd = *g;
+        gd.yb = g->yb - n > g->y0 ? g->yb - n : g->y0;
+        gd.ye = g->ye + n < g->y0 + g->rows ? g->ye + n : g->y0 + g->rows;
+        rc = fs_k_divergence(&gd, u, v, div, stream);
+        if (rc) return rc;
+    }
+    return run_sweeps<OP_PRESSURE>(t, g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div,
+                                   cfl_dev);
+}
+
+int diffuse_n(const JacobiTuning &t, const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
+              float deltaTime, int n, int *result_in_b, void *stream)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE_FS("fs_k_diffuse_n", a && b && a != b, "bad pointers");
+    REQUIRE_FS("fs_k_diffuse_n", nplanes >= 1 && nplanes <= 4, "nplanes must be 1..4");
+    REQUIRE_FS("fs_k_diffuse_n", n >= 0, "negative sweep count");
+    if (result_in_b) *result_in_b = 0;
+    if (g->ye <= g->yb || n == 0) return FS_OK;
+    float ca, cden;
+    diffuse_coeffs(g, viscosity, deltaTime, &ca, &cden);
+    return run_sweeps<OP_DIFFUSE>(t, g, nullptr, a, b, false, nplanes, plane_stride, ca, cden, n, result_in_b, (hipStream_t)stream);
 }
 
 }  // namespace fs
@@ -576,17 +656,7 @@ int fs_selftest_divide(float den, unsigned long long *mismatches_host)
 int fs_k_pressureSolve_n(const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero,
                          int *result_in_b, void *stream)
 {
-    int rc = check_grid(g);
-    if (rc) return rc;
-    REQUIRE(div && pa && pb && pa != pb, "bad pointers");
-    REQUIRE(n >= 0, "negative sweep count");
-    if (result_in_b) *result_in_b = 0;
-    if (g->ye <= g->yb) return FS_OK;
-    if (n == 0) {
-        if (p_is_zero) return fs_k_clear(g, pa, 1, 0, stream);
-        return FS_OK;
-    }
-    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream);
+    return fs::pressure_n(fs::default_tuning(), g, div, pa, pb, n, p_is_zero, result_in_b, stream);
 }
 
 int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero,
@@ -599,35 +669,20 @@ int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa,
     if (result_in_b) *result_in_b = 0;
     if (g->ye <= g->yb) return FS_OK;
     // (the launches before the last leave one more row of p exact on each side: the gradient reads it)
-    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v);
+    return run_sweeps<OP_PRESSURE>(fs::default_tuning(), g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b,
+                                   (hipStream_t)stream, u, v);
 }
 
 int fs_k_project_n_cfl(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
                        int *result_in_b, void *stream)
 {
-    int rc = check_grid(g);
-    if (rc) return rc;
-    REQUIRE(u && v && div && pa && pb && pa != pb, "bad pointers");
-    REQUIRE(n >= 1, "needs at least one sweep");
-    if (result_in_b) *result_in_b = 0;
-    if (g->ye <= g->yb) return FS_OK;
-    if (jacobi_launch_count(OP_PRESSURE, n) < 2) {
-        // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads):
-        // the divergence of the rows the sweeps read stays a separate pass
-        fs_grid gd = *g;
-        gd.yb = g->yb - n > g->y0 ? g->yb - n : g->y0;
-        gd.ye = g->ye + n < g->y0 + g->rows ? g->ye + n : g->y0 + g->rows;
-        rc = fs_k_divergence(&gd, u, v, div, stream);
-        if (rc) return rc;
-    }
-    return run_sweeps<OP_PRESSURE>(g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div,
-                                   cfl_dev);
+    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, cfl_dev, result_in_b, stream);
 }
 
 int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, int *result_in_b,
                    void *stream)
 {
-    return fs_k_project_n_cfl(g, u, v, div, pa, pb, n, nullptr, result_in_b, stream);
+    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, nullptr, result_in_b, stream);
 }
 
 int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)
@@ -637,31 +692,14 @@ int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float
     REQUIRE(div && p && pOut && p != pOut, "bad pointers");
     if (g->ye <= g->yb) return FS_OK;
     // one sweep: a is only read
-    return run_sweeps<OP_PRESSURE>(g, div, const_cast<float *>(p), pOut, false, 1, 0, 0.f, 1.f, 1, nullptr,
+    return run_sweeps<OP_PRESSURE>(fs::default_tuning(), g, div, const_cast<float *>(p), pOut, false, 1, 0, 0.f, 1.f, 1, nullptr,
                                    (hipStream_t)stream);
-}
-
-static void diffuse_coeffs(const fs_grid *g, float viscosity, float dt, float *a, float *den)
-{
-    // Shaders:96  a = deltaTime * viscosity * width * height  (uint -> float)
-    *a = ((dt * viscosity) * (float)(unsigned)g->width) * (float)(unsigned)g->height;
-    *den = 1.0f + 4.0f * *a;  // Shaders:103
 }
 
 int fs_k_diffuse_n(const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
                    float deltaTime, int n, int *result_in_b, void *stream)
 {
-    int rc = check_grid(g);
-    if (rc) return rc;
-    REQUIRE(a && b && a != b, "bad pointers");
-    REQUIRE(nplanes >= 1 && nplanes <= 4, "nplanes must be 1..4");
-    REQUIRE(n >= 0, "negative sweep count");
-    if (result_in_b) *result_in_b = 0;
-    if (g->ye <= g->yb || n == 0) return FS_OK;
-    float ca, cden;
-    diffuse_coeffs(g, viscosity, deltaTime, &ca, &cden);
-    return run_sweeps<OP_DIFFUSE>(g, nullptr, a, b, false, nplanes, plane_stride, ca, cden, n, result_in_b,
-                                  (hipStream_t)stream);
+    return fs::diffuse_n(fs::default_tuning(), g, a, b, nplanes, plane_stride, viscosity, deltaTime, n, result_in_b, stream);
 }
 
 int fs_k_diffuse(const fs_grid *g, const float *in, float *out, int nplanes, size_t plane_stride, float viscosity,
@@ -674,7 +712,7 @@ int fs_k_diffuse(const fs_grid *g, const float *in, float *out, int nplanes, siz
     if (g->ye <= g->yb) return FS_OK;
     float ca, cden;
     diffuse_coeffs(g, viscosity, deltaTime, &ca, &cden);
-    return run_sweeps<OP_DIFFUSE>(g, nullptr, const_cast<float *>(in), out, false, nplanes, plane_stride, ca, cden, 1,
+    return run_sweeps<OP_DIFFUSE>(fs::default_tuning(), g, nullptr, const_cast<float *>(in), out, false, nplanes, plane_stride, ca, cden, 1,
                                   nullptr, (hipStream_t)stream);
 }
 

@@ -28,7 +28,9 @@ struct Quad {
 
 __device__ __forceinline__ Quad quad_of_thread(const GK &g, int yb, int ye)
 {
-    const uint2 t = xcd_tile<XCD_BAND>();
+    // thin launches (the rims of a slab's split advection: a few dozen rows) are dispatched unpadded and in plain order:
+    // padded to the 64 tile rows of one round of XCD bands they were mostly workgroups that exit at once (quad_grid)
+    const uint2 t = gridDim.y < 8u * XCD_BAND ? make_uint2(blockIdx.x, blockIdx.y) : xcd_tile<XCD_BAND>();
     Quad q;
     q.x = (t.x * BX + threadIdx.x) * 4;
     q.y = yb + t.y * BY + threadIdx.y;
@@ -728,7 +730,8 @@ __global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const flo
 static inline dim3 quad_grid(const fs_grid *g, int nplanes)
 {
     int qx = g->pitch / 4;
-    return dim3((qx + BX - 1) / BX, xcd_pad_rows((g->ye - g->yb + BY - 1) / BY, XCD_BAND), nplanes);
+    const unsigned tile_rows = (unsigned)((g->ye - g->yb + BY - 1) / BY);
+    return dim3((qx + BX - 1) / BX, tile_rows < 8u * XCD_BAND ? tile_rows : xcd_pad_rows(tile_rows, XCD_BAND), nplanes);
 }
 static const dim3 kBlock(BX, BY, 1);
 

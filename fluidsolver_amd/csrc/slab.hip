@@ -46,7 +46,6 @@
 
 namespace fs {
 
-int jacobi_launch_count(int op, int n);   // jacobi.hip
 
 void slab_rows(int H, int world, int rank, int *r0, int *r1)
 {
@@ -190,6 +189,7 @@ struct Planner {
             const fs_grid g = grid_of(c, out_depth);
             float *src = F.p(), *dst = F.t();
             hipStream_t st = lane ? lane : c->stream;
+            const JacobiTuning tn = c->tuning;
             if (pressure) {
                 const int pz = c->p_zero ? 1 : 0;
                 c->p_zero = false;
@@ -199,13 +199,13 @@ struct Planner {
                     float *dw = c->f[F_DIV].p();
                     compute("project_n", g, n, [=]() {                                // Solver:522-547
                         int ib = 0;
-                        return fs_k_project_n(&g, u, v, dw, src, dst, n, &ib, st);
+                        return project_n_cfl(tn, &g, u, v, dw, src, dst, n, nullptr, &ib, st);
                     });
                 }
                 else
                     compute("pressure_n", g, n, [=]() {                               // Solver:533-541
                         int ib = 0;
-                        return fs_k_pressureSolve_n(&g, div, src, dst, n, pz, &ib, st);
+                        return pressure_n(tn, &g, div, src, dst, n, pz, &ib, st);
                     });
             } else {
                 const float coeff = fi == F_VEL ? c->params.viscosity : c->params.diffusion;
@@ -221,17 +221,17 @@ struct Planner {
                 hipEvent_t ef = c->ev_fork, ej = c->ev_join;
                 compute("diffuse_n", g, n, [=]() {                                    // Solver:506-517, :563-573
                     int ib = 0;
-                    if (!split) return fs_k_diffuse_n(&g, src, dst, np, plane, coeff, dt, n, &ib, st);
+                    if (!split) return diffuse_n(tn, &g, src, dst, np, plane, coeff, dt, n, &ib, st);
                     FS_HIP(hipEventRecord(ef, st));
                     FS_HIP(hipStreamWaitEvent(st2, ef, 0));
-                    const int rc1 = fs_k_diffuse_n(&g, src, dst, 1, plane, coeff, dt, n, &ib, st);
-                    const int rc2 = fs_k_diffuse_n(&g, src + plane, dst + plane, np - 1, plane, coeff, dt, n, &ib, st2);
+                    const int rc1 = diffuse_n(tn, &g, src, dst, 1, plane, coeff, dt, n, &ib, st);
+                    const int rc2 = diffuse_n(tn, &g, src + plane, dst + plane, np - 1, plane, coeff, dt, n, &ib, st2);
                     FS_HIP(hipEventRecord(ej, st2));           // joined even after an error: a capture must end whole
                     FS_HIP(hipStreamWaitEvent(st, ej, 0));
                     return rc1 ? rc1 : rc2;
                 });
             }
-            if (jacobi_launch_count(pressure ? 0 : 1, n) & 1) F.cur ^= 1;
+            if (jacobi_launch_count(c->tuning, pressure ? 0 : 1, n) & 1) F.cur ^= 1;
             if (multi) F.valid = out_depth;
             remaining -= n;
         }
@@ -357,13 +357,14 @@ struct Planner {
             const fs_grid g = grid_of(c, 0);
             Field &P = c->f[F_P];
             float *u = V.p(), *v = off(u, plane), *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = c->cfl_dev;
+            const JacobiTuning tn = c->tuning;
             compute("project_n_cfl", g, N, [=]() {                                    // :522-547 + the CFL bound
                 hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
                 if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
                 int ib = 0;
-                return fs_k_project_n_cfl(&g, u, v, dw, src, dst, N, cfl, &ib, st);
+                return project_n_cfl(tn, &g, u, v, dw, src, dst, N, cfl, &ib, st);
             });
-            if (jacobi_launch_count(0, N) & 1) P.cur ^= 1;
+            if (jacobi_launch_count(c->tuning, 0, N) & 1) P.cur ^= 1;
             P.valid = 0;
             c->f[F_DIV].valid = 0;
             c->p_zero = false;
@@ -787,11 +788,12 @@ int tracer_phase(fs_ctx *c, int phase)
         FS_HIP(hipMemcpyAsync(c->tr_counts_host, c->tr_counts_dev, (size_t)W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         FS_HIP(hipStreamSynchronize(c->stream));
         if (cm->kind == 1) {
-            for (int i = 0; i < W * W; ++i) c->tr_matrix_host[i] = 0.0f;
-            for (int d = 0; d < W; ++d) c->tr_matrix_host[me * W + d] = (float)c->tr_counts_host[d];
-            FS_HIP(hipMemcpyAsync(c->tr_matrix_dev, c->tr_matrix_host, (size_t)W * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            FS_NCCL(g_rccl.AllReduce(c->tr_matrix_dev, c->tr_matrix_dev, (size_t)W * W, ncclFloat, ncclSum, (ncclComm_t)cm->nccl, c->stream));
-            FS_HIP(hipMemcpyAsync(c->tr_matrix_host, c->tr_matrix_dev, (size_t)W * W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            for (int i = 0; i < W * W; ++i) c->tr_matrix_host[i] = 0;
+            for (int d = 0; d < W; ++d) c->tr_matrix_host[me * W + d] = c->tr_counts_host[d];
+            FS_HIP(hipMemcpyAsync(c->tr_matrix_dev, c->tr_matrix_host, (size_t)W * W * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            // integer counts: as floats they would round above 2^24 per pair and the grouped send / recv sizes would stop matching
+            FS_NCCL(g_rccl.AllReduce(c->tr_matrix_dev, c->tr_matrix_dev, (size_t)W * W, ncclInt32, ncclSum, (ncclComm_t)cm->nccl, c->stream));
+            FS_HIP(hipMemcpyAsync(c->tr_matrix_host, c->tr_matrix_dev, (size_t)W * W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             FS_HIP(hipStreamSynchronize(c->stream));
         }
         return FS_OK;

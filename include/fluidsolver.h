@@ -69,8 +69,10 @@ typedef struct fs_grid {
 /* smallest legal pitch for a width */
 int fs_pitch_for_width(int width);
 
-/* Process-wide tuning knobs of the per-kernel layer (keys: FS_OPT_BLOCK_DEPTH = sweeps fused
- * per Jacobi launch, 1..48; FS_OPT_BLOCK_DEPTH_PRESSURE / _DIFFUSE; FS_OPT_TILE_VARIANT).  No reference counterpart. */
+/* Process-wide DEFAULT of the Jacobi tuning knobs (keys: FS_OPT_BLOCK_DEPTH = sweeps fused per Jacobi launch, 1..48;
+ * FS_OPT_BLOCK_DEPTH_PRESSURE / _DIFFUSE; FS_OPT_TILE_VARIANT / _DIFFUSE; FS_OPT_STAGGER / _MODE): what the per-kernel entry
+ * points fs_k_*_n use and what a context created afterwards starts from.  A context keeps a copy of its own, changed
+ * with fs_set_option, so two contexts in one process never change each other's tuning.  No reference counterpart. */
 int fs_config_set(int key, int value);
 int fs_config_get(int key);
 
@@ -265,17 +267,17 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      the projection in one loop where each pays (size rules in DESIGN.md), both advections in one pass and
                                      curl + confinement in one pass for out-of-cache planes; 2 = fade only; 3 = projection loop only, at any size; 4 = every fusion at any
                                      size (tests); 0 = none */
-       FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* fs_config_set/get only: depth of the pressure loop, default 10 */
-       FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* fs_config_set/get only: depth of the diffuse loops, default 8 */
-       FS_OPT_STAGGER = 7,        /* fs_config_set/get only: start delay (10 ns ticks) of every other resident
+       FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* depth of the pressure loop, default 10 */
+       FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* depth of the diffuse loops, default 8 */
+       FS_OPT_STAGGER = 7,        /* start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
-       FS_OPT_STAGGER_MODE = 8,   /* fs_config_set only: which workgroups are held back (tuning) */
+       FS_OPT_STAGGER_MODE = 8,   /* which workgroups are held back, 0..3 (tuning) */
        FS_OPT_SPLIT_PLANES = 12,  /* 1 (default): the independent planes of a diffuse loop run as two concurrent chains of
                                      launches (a second stream, fork/join by event; parallel branches of the frame's graph),
                                      so the partly filled last round of one launch is filled by the other chain, and the dye diffusion loop
                                      of a single-GPU frame runs beside the velocity chain (third stream); 0 = one chain */
        FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
-       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* fs_config_set/get only: tile shape of the diffuse loops alone */
+       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
                                      depth); 0 = exchange, wait, compute */
@@ -290,7 +292,7 @@ int fs_reset(fs_ctx *ctx);                                   /* reset(), Solver:
 int fs_default_params(fs_params *p);                         /* defaults of Solver:139-202 */
 int fs_set_params(fs_ctx *ctx, const fs_params *p);
 int fs_get_params(fs_ctx *ctx, fs_params *p);
-int fs_set_option(fs_ctx *ctx, int option, int value);
+int fs_set_option(fs_ctx *ctx, int option, int value);   /* the tuning keys of fs_config_set change THIS context's copy only */
 
 /* applyForce(position:force:color:), Solver:444-470, in GRID units (the 5 addForces
  * arguments; color alpha is accepted for signature parity and ignored). */

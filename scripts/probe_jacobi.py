@@ -21,7 +21,7 @@ def t(stage):
     return ms.value * 1e3 / reps
 for rep in range(2):
   for depth in (10,):
-    L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
+    L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH, depth))[1])
     for name, mode in (("full", 0), ("no sweeps (memory only)", 16), ("no loads (compute+store)", 32), ("neither", 48)):
-        L.check(lib.fs_config_set(L.OPT_STAGGER_MODE, mode)); L.check(lib.fs_config_set(L.OPT_STAGGER, 0))
+        L.check((lib.fs_config_set(L.OPT_STAGGER_MODE, mode), lib.fs_set_option(s.ctx, L.OPT_STAGGER_MODE, mode))[1]); L.check((lib.fs_config_set(L.OPT_STAGGER, 0), lib.fs_set_option(s.ctx, L.OPT_STAGGER, 0))[1])
         print("depth %2d %-28s pressure x%d: %7.1f us  diffuse x%d: %7.1f us" % (depth, name, N, t(L.STAGE_PRESSURE), N, t(L.STAGE_DIFFUSE_VELOCITY)), flush=True)

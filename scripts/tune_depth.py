@@ -22,7 +22,7 @@ for opt, stage, name in ((L.OPT_BLOCK_DEPTH_PRESSURE, L.STAGE_PRESSURE_CLEARED, 
                          (L.OPT_BLOCK_DEPTH_DIFFUSE, L.STAGE_DIFFUSE_VELOCITY, "diffuse(velocity)")):
     keep = lib.fs_config_get(opt)
     for depth in (5, 6, 7, 8, 10, 12, 14, 16, 20):
-        lib.fs_config_set(opt, depth)
+        (lib.fs_config_set(opt, depth), lib.fs_set_option(s.ctx, opt, depth))[1]
         for rep in range(2):
             L.check(lib.fs_stage(s.ctx, stage, 40), s.ctx); s.sync()
             L.check(lib.fs_timer_begin(s.ctx), s.ctx)
@@ -30,4 +30,4 @@ for opt, stage, name in ((L.OPT_BLOCK_DEPTH_PRESSURE, L.STAGE_PRESSURE_CLEARED, 
                 L.check(lib.fs_stage(s.ctx, stage, 40), s.ctx)
             L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
         print("%-18s depth %2d  %9.1f us per 40 sweeps" % (name, depth, ms.value * 1e3 / reps), flush=True)
-    lib.fs_config_set(opt, keep)
+    (lib.fs_config_set(opt, keep), lib.fs_set_option(s.ctx, opt, keep))[1]

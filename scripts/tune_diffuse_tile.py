@@ -16,7 +16,7 @@ names = {4: "4x16", 7: "5x16", 6: "6x16"}
 for rep in range(3):
     for var in (4, 7):
         for depth in (6, 7, 8, 9, 10, 12):
-            L.check(lib.fs_config_set(L.OPT_TILE_VARIANT_DIFFUSE, var)); L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, depth))
+            L.check((lib.fs_config_set(L.OPT_TILE_VARIANT_DIFFUSE, var), lib.fs_set_option(s.ctx, L.OPT_TILE_VARIANT_DIFFUSE, var))[1]); L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, depth), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH_DIFFUSE, depth))[1])
             s.stage(L.STAGE_DIFFUSE_VELOCITY, 40); s.sync()
             L.check(lib.fs_timer_begin(s.ctx), s.ctx)
             for _ in range(20):

@@ -25,7 +25,7 @@ for var in VARS:
     for depth in (5, 7, 8, 10, 12, 14, 16, 20):
         if th[var] - 2 * depth < 8:
             continue
-        L.check(lib.fs_config_set(L.OPT_TILE_VARIANT, var)); L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth))
+        L.check((lib.fs_config_set(L.OPT_TILE_VARIANT, var), lib.fs_set_option(s.ctx, L.OPT_TILE_VARIANT, var))[1]); L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH, depth))[1])
         row = [names[var], depth]
         for stage in (L.STAGE_PRESSURE, L.STAGE_DIFFUSE_VELOCITY):
             s.stage(stage, N); s.sync()

@@ -19,12 +19,12 @@ ms = C.c_float()
 VAR = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 DP = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 DD = int(sys.argv[6]) if len(sys.argv) > 6 else 8
-L.check(lib.fs_config_set(L.OPT_TILE_VARIANT, VAR))
-L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, DP)); L.check(lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, DD))
+L.check((lib.fs_config_set(L.OPT_TILE_VARIANT, VAR), lib.fs_set_option(s.ctx, L.OPT_TILE_VARIANT, VAR))[1])
+L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH_PRESSURE, DP), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH_PRESSURE, DP))[1]); L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH_DIFFUSE, DD), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH_DIFFUSE, DD))[1])
 print("variant", VAR, "depth pressure", DP, "diffuse", DD)
 for mode in (0, 3):
     for ticks in (0, 200, 400, 600, 800, 1000):
-        L.check(lib.fs_config_set(L.OPT_STAGGER_MODE, mode)); L.check(lib.fs_config_set(L.OPT_STAGGER, ticks))
+        L.check((lib.fs_config_set(L.OPT_STAGGER_MODE, mode), lib.fs_set_option(s.ctx, L.OPT_STAGGER_MODE, mode))[1]); L.check((lib.fs_config_set(L.OPT_STAGGER, ticks), lib.fs_set_option(s.ctx, L.OPT_STAGGER, ticks))[1])
         row = []
         for stage in (L.STAGE_PRESSURE, L.STAGE_DIFFUSE_VELOCITY):
             s.stage(stage, N); s.sync()

@@ -229,7 +229,8 @@ ncclResult_t ncclAllReduce(const void *sendbuf, void *recvbuf, size_t count, ncc
                            ncclComm_t comm, hipStream_t st)
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
-    if (!c || dt != ncclFloat || count > MAX_AR || (op != ncclMax && op != ncclSum && op != ncclMin)) return ncclInvalidArgument;
+    if (!c || (dt != ncclFloat && dt != ncclInt32) || count > MAX_AR || (op != ncclMax && op != ncclSum && op != ncclMin)) return ncclInvalidArgument;
+    if (dt == ncclInt32 && op != ncclSum) return ncclInvalidArgument;
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
     const uint64_t g = c->ar_gen++, n = (uint64_t)c->nranks;
     Header *h = c->hdr;
@@ -243,7 +244,16 @@ ncclResult_t ncclAllReduce(const void *sendbuf, void *recvbuf, size_t count, ncc
                   "the other ranks' all-reduce (collectives issued in a different order?)", c))
         return ncclSystemError;
     std::vector<float> r(count);
-    for (size_t i = 0; i < count; ++i) {
+    for (size_t i = 0; i < count && dt == ncclInt32; ++i) {   // 32-bit integer sum: the same 4-byte slots, read as ints
+        int acc = 0;
+        for (int q = 0; q < c->nranks; ++q) {
+            int v;
+            memcpy(&v, &h->ar_vals[g & 1][q][i], sizeof(v));
+            acc += v;
+        }
+        memcpy(&r[i], &acc, sizeof(acc));
+    }
+    for (size_t i = 0; i < count && dt == ncclFloat; ++i) {
         float acc = h->ar_vals[g & 1][0][i];
         for (int q = 1; q < c->nranks; ++q) {
             const float v = h->ar_vals[g & 1][q][i];

@@ -628,3 +628,45 @@ def test_config3_full_size_matches_oracle(oracle_omp):
         assert (got[2] != 0).any()   # some tracers did pick up fluid velocity
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+def test_jacobi_tuning_is_per_context():
+    # two contexts in one process: fs_set_option on one (block depth, tile shape) leaves the other's launches alone
+    # (they used to share process-wide statics), and both still produce the same bits
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.script import splat
+    lib = L.load()
+    W, H = 700, 330
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 23)
+    a, b = FluidSolver(W, H), FluidSolver(W, H)
+    try:
+        for s in (a, b):
+            (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+            s.displayMode = None
+        a.set_option(L.OPT_BLOCK_DEPTH, 3)
+        a.set_option(L.OPT_TILE_VARIANT, 0)
+        assert lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE) == 10 and lib.fs_config_get(L.OPT_TILE_VARIANT) == 4
+        import ctypes as C
+        from oracle_binding import full_grid   # noqa: F401  (plan dump needs no GPU; the launch counts show the depth in use)
+        for f in range(3):
+            for s in (a, b):
+                pos, force, col = splat(W, H, f)
+                s.applyForce(pos, force, col)
+                s.update()
+        a.sync(); b.sync()
+        for fld in (L.FIELD_VELOCITY, L.FIELD_DENSITY, L.FIELD_PRESSURE):
+            assert np.array_equal(a.read_field(fld), b.read_field(fld))
+        # 23 sweeps: depth 3 -> 8 launches (even: result in the first buffer), depth 10 -> 3 launches (odd): the two contexts'
+        # pressure ping-pong sides differ after a frame, which only happens if each used its own depth
+        pa, pb = C.c_void_p(), C.c_void_p()
+        L.check(lib.fs_field_device_ptr(a.ctx, L.FIELD_PRESSURE, 0, C.byref(pa), None), a.ctx)
+        a.update(); a.sync()
+        L.check(lib.fs_field_device_ptr(a.ctx, L.FIELD_PRESSURE, 0, C.byref(pb), None), a.ctx)
+        assert pa.value == pb.value        # even number of launches: same side every frame
+        L.check(lib.fs_field_device_ptr(b.ctx, L.FIELD_PRESSURE, 0, C.byref(pa), None), b.ctx)
+        b.update(); b.sync()
+        L.check(lib.fs_field_device_ptr(b.ctx, L.FIELD_PRESSURE, 0, C.byref(pb), None), b.ctx)
+        assert pa.value != pb.value        # odd number of launches: the sides alternate
+    finally:
+        a.close(); b.close()
