@@ -430,6 +430,7 @@ def main():
     t0 = time.perf_counter()
     for f in range(f0 + args.warmup, f0 + args.warmup + args.steps):
         step(f)
+    t_enq = time.perf_counter() - t0     # host side only: the calls have returned, the GPU may still be running
     sync_all()
     barrier()
     sync_all()
@@ -458,6 +459,7 @@ def main():
                    "jacobi_block_depth": {"pressure": lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE),
                                           "diffuse": lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE)}},
         "frames_per_s": fps,
+        "host_enqueue_us_per_frame": t_enq * 1e6 / args.steps,
     }
 
     phase("micro-benchmarks / CPU baseline / exposed waits")
@@ -519,7 +521,13 @@ def main():
         exposed = {"velocity_halo": float(wt[0]) * 1e3 / pf, "dye_halo": float(wt[1]) * 1e3 / pf,
                    "blocking_exchanges": float(wt[2]) * 1e3 / pf,
                    "note": "us per frame the kernels waited at joins (max over ranks, HIP events, 10 extra frames)"}
-        out["slab"] = {"exposed_wait_us_per_frame": exposed,"check": slab_check, "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+        te = torch.tensor([t_enq], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        out["slab"] = {"exposed_wait_us_per_frame": exposed, "check": slab_check,
+                       "host_enqueue_us_per_frame": float(te.item()) * 1e6 / args.steps,
+                       "host_enqueue_note": "wall time of the fs_add_force + fs_step calls of the timed frames on the slowest rank, before "
+                                            "any synchronisation (includes the host wait for the CFL all-reduce that sizes the advection "
+                                            "halo); the frame is host-bound when this approaches ms_per_step", "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
                        "overlap": bool(overlap), "advection_replans": st["redo"],

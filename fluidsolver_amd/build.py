@@ -44,7 +44,7 @@ def build(force=False, verbose=True, probe=False):
     if not probe and not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + (["-DFS_PROBE"] if probe else []) + ["-o", LIB_PROBE if probe else LIB] + \
+    cmd = [hipcc] + FLAGS + (["-DFS_PROBE"] + os.environ.get("FS_PROBE_DEFINES", "").split() if probe else []) + ["-o", LIB_PROBE if probe else LIB] + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -21,6 +21,7 @@ struct JacobiTuning {
     int depth[2];      // sweeps fused per launch: [0] pressure, [1] diffuse
     int variant[2];    // register-tile shape, see launch_block
     int stagger, stagger_mode;
+    int band_delay;    // two-band projection: head start of band A over band B, 10 ns ticks (FS_OPT_BAND_DELAY)
 };
 JacobiTuning &default_tuning();
 int tuning_set(JacobiTuning &t, int key, int value);   // key = FS_OPT_*; FS_ERR_INVALID for an unknown key or a bad value
@@ -33,6 +34,10 @@ int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, f
                   int *result_in_b, void *stream);
 int diffuse_n(const JacobiTuning &t, const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
               float deltaTime, int n, int *result_in_b, void *stream);
+// the projection as two row bands on two streams (jacobi.hip); events are hipEvent_t
+int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u, float *v, float *div, float *pa, float *pb,
+                    float *qa, float *qb, int n, int *result_in_b, void *stream_a, void *stream_b, void *ev_fork, void *ev_join,
+                    void *ev_first_a, void *ev_first_b);
 
 void set_error(const char *fmt, ...);
 const char *get_error();

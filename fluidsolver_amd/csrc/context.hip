@@ -236,6 +236,8 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_band[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_band[1], hipEventDisableTiming);
         if (e != hipSuccess) rc = fs::hip_fail(e, "second stream / events");
     }
     if (!rc && world > 1) {
@@ -330,6 +332,10 @@ int fs_destroy(fs_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork3) (void)hipEventDestroy(c->ev_fork3);
     if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_band[i]) (void)hipEventDestroy(c->ev_band[i]);
+        (void)hipFree(c->p_band[i]);
+    }
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -358,6 +364,7 @@ int fs_reset(fs_ctx *c)
     TRYHIP(c, hipMemsetAsync(c->display, 0, 4 * pb, c->stream));
     TRYHIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
     for (int &h : c->halo_hist) h = -1;
+    c->p_band_dirty = false;
     return FS_OK;
 }
 
@@ -390,7 +397,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     switch (option) {
     case FS_OPT_USE_GRAPH: c->use_graph = value ? 1 : 0; break;
     case FS_OPT_BLOCK_DEPTH: case FS_OPT_BLOCK_DEPTH_PRESSURE: case FS_OPT_BLOCK_DEPTH_DIFFUSE:
-    case FS_OPT_TILE_VARIANT: case FS_OPT_TILE_VARIANT_DIFFUSE: case FS_OPT_STAGGER: case FS_OPT_STAGGER_MODE:
+    case FS_OPT_TILE_VARIANT: case FS_OPT_TILE_VARIANT_DIFFUSE: case FS_OPT_STAGGER: case FS_OPT_STAGGER_MODE: case FS_OPT_BAND_DELAY:
         // this context's own copy: another context in the process keeps its tuning (fs_config_set changes the default)
         if (fs::tuning_set(c->tuning, option, value)) { fs::set_error("option %d: value %d out of range", option, value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
@@ -399,6 +406,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
     case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
     case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
     case FS_OPT_SPLIT_PLANES: c->split_planes = value ? 1 : 0; break;
+    case FS_OPT_SPLIT_ROWS: c->split_rows = value ? 1 : 0; break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     drop_graphs(c);
@@ -441,6 +449,19 @@ int fs_step(fs_ctx *c)
         TRY(c, fs::run_frame(c));
         return FS_OK;
     }
+    // band B of a two-band projection iterates in two private planes (allocated here, outside any capture)
+    if (!c->p_band[0] && fs::bands_wanted(c)) {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipMalloc((void **)&c->p_band[i], c->plane * sizeof(float));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(c->p_band[0]);
+                c->p_band[0] = c->p_band[1] = nullptr;   // the planner then keeps the loop in one chain
+                break;
+            }
+        }
+    }
+    struct Mark { fs_ctx *c; ~Mark() { c->p_band_dirty = c->p_band_active; } } mark{c};   // after the frame, however it ran
     // Scalars are baked into the recorded kernel nodes, so a change of parameters invalidates the graphs.  A host
     // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
     // host time) until the parameters have stayed put for two frames, and only then is a graph recorded again.
@@ -499,6 +520,17 @@ int fs_sync(fs_ctx *c)
     return FS_OK;
 }
 
+// After a frame projected in two row bands the lower band's pressure still sits in the band's private plane: bring
+// it home before anything looks at the pressure field (nothing in update() does: p is cleared every frame).
+static int settle_pressure(fs_ctx *c)
+{
+    if (!c->p_band_dirty) return FS_OK;
+    c->p_band_dirty = false;
+    const size_t o = (size_t)c->p_band_row * c->pitch, n = (size_t)(c->H - c->p_band_row) * c->pitch;
+    TRYHIP(c, hipMemcpyAsync(c->f[F_P].p() + o, c->p_band[c->p_band_final] + o, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return FS_OK;
+}
+
 // Host copies move the rows this context OWNS: dense planar [plane][r1-r0][width] (the whole field on one GPU).
 static int copy_field(fs_ctx *c, int field, float *host, size_t bytes, bool to_host, const char *who)
 {
@@ -507,6 +539,7 @@ static int copy_field(fs_ctx *c, int field, float *host, size_t bytes, bool to_h
     const size_t rows = (size_t)(c->r1 - c->r0);
     const size_t need = (size_t)np * c->W * rows * sizeof(float);
     if (bytes != need) { fs::set_error("%s: expected %zu bytes, got %zu", who, need, bytes); return ctx_fail(c, FS_ERR_INVALID); }
+    if (field == FS_FIELD_PRESSURE) TRY(c, settle_pressure(c));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     float *dev = field_ptr(c, field) + (size_t)(c->r0 - c->b0) * c->pitch;
     const size_t hp = (size_t)c->W * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
@@ -540,6 +573,7 @@ int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pi
     if (!c || !dev_ptr) return FS_ERR_INVALID;
     const int np = nplanes_of(field);
     if (plane < 0 || plane >= np) { fs::set_error("bad field/plane %d/%d", field, plane); return ctx_fail(c, FS_ERR_INVALID); }
+    if (field == FS_FIELD_PRESSURE) TRY(c, settle_pressure(c));
     *dev_ptr = field_ptr(c, field) + (size_t)plane * c->plane;
     if (pitch) *pitch = c->pitch;
     return FS_OK;
@@ -570,6 +604,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
     CTX(c);
     SINGLE(c, "fs_stage");
     if (n < 0) { fs::set_error("negative sweep count"); return ctx_fail(c, FS_ERR_INVALID); }
+    TRY(c, settle_pressure(c));
     float *u = c->f[F_VEL].p(), *v = u + c->plane;
     int rc;
     switch (stage) {

@@ -115,6 +115,15 @@ struct fs_ctx {
     int split_planes = 1;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the projection of a single-GPU frame as two row bands on stream / stream2 (project_n_bands): band B iterates in
+    // two private planes, so after such a frame the rows [p_band_row, H) of the pressure field live in
+    // p_band[p_band_final] until settle_pressure() copies them home (only a read-back of the pressure asks for that)
+    int split_rows = 1;                 // FS_OPT_SPLIT_ROWS
+    float *p_band[2] = {nullptr, nullptr};
+    hipEvent_t ev_band[2] = {nullptr, nullptr};
+    bool p_band_active = false;         // planner: the current plan projects in two bands
+    bool p_band_dirty = false;          // a frame has run since the rows were last copied home
+    int p_band_row = 0, p_band_final = 0;
     // the dye diffusion loop of a single-GPU frame runs beside the whole velocity chain on a third stream
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
@@ -162,6 +171,7 @@ void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient 
 void plan_update_b(fs_ctx *c, int h);   // advection .. particles, with advection halo h
 int run_frame(fs_ctx *c);               // plan + execute one update() on this context (world 1 or RCCL)
 int run_frames(fs_ctx **cs, int n);     // ... on all n slabs of an in-process group, in lock step
+bool bands_wanted(const fs_ctx *c);     // will the planner project this context's frames in two row bands?
 
 }  // namespace fs
 

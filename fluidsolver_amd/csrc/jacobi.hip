@@ -28,6 +28,30 @@ namespace fs {
 
 enum { OP_PRESSURE = 0, OP_DIFFUSE = 1 };
 
+#ifdef FS_PROBE
+// Timeline of the workgroups of the LAST k_jacobi_block launch (probe build only, scripts/jacobi_timeline.py):
+// per workgroup 8 words -- 100 MHz clock at entry / tile loaded / sweeps done / exit, HW_ID, XCC_ID.
+#define FS_TL_MAX 8192
+__device__ unsigned long long g_timeline[8 * FS_TL_MAX];
+__device__ __forceinline__ void tl_stamp(int slot)
+{
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == blockDim.x / 2 && lin < FS_TL_MAX) {   // a wave in the middle of the tile: it runs every sweep and stores
+        g_timeline[8 * lin + slot] = wall_clock64();
+        if (slot == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_timeline[8 * lin + 4] = hw;
+            g_timeline[8 * lin + 5] = xcc;
+        }
+    }
+}
+#define FS_TL(slot) tl_stamp(slot)
+#else
+#define FS_TL(slot)
+#endif
+
 struct JacobiArgs {
     GK g;
     int yb, ye;        // global rows this launch must produce
@@ -108,8 +132,17 @@ __device__ __forceinline__ Row sweep_row(const Row &c, const Row &up, const Row 
         const v2f av = {a, a};
         const v2f xa = c.a + av * ((v2f{t0, t1} + up.a) + dn.a);
         const v2f xb = c.b + av * ((v2f{t2, t3} + up.b) + dn.b);
+#ifdef FS_PROBE_FASTDIV   // timing experiment only: unguarded q0 = x r; n = q0 den - x; q = q0 - n r
+        const float rf = (float)rden, denf = (float)(1.0 / rden);
+        const v2f rv = {rf, rf}, dv = {denf, denf};
+        const v2f qa0 = xa * rv, qb0 = xb * rv;
+        const v2f na = __builtin_elementwise_fma(qa0, dv, -xa), nb = __builtin_elementwise_fma(qb0, dv, -xb);
+        n.a = __builtin_elementwise_fma(na, -rv, qa0);
+        n.b = __builtin_elementwise_fma(nb, -rv, qb0);
+#else
         n.a = v2f{div_const(xa.x, rden), div_const(xa.y, rden)};
         n.b = v2f{div_const(xb.x, rden), div_const(xb.y, rden)};
+#endif
     }
     return n;
 }
@@ -124,15 +157,9 @@ __device__ __forceinline__ void sweep_once(const Row (&src)[R], Row (&dst)[R], c
 {
     xch[buf][wave][0][lane] = f4_of(src[0]);
     xch[buf][wave][1][lane] = f4_of(src[R - 1]);
-    __syncthreads();
-    const Row above = row_of(xch[buf][wup][1][lane]);    // row above this wave's strip
-    const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const Row &c = src[i];
-        const Row &up = i > 0 ? src[i - 1] : above;
-        const Row &nx = i < R - 1 ? src[i + 1] : below;
-        Row n = sweep_row<OP>(c, up, nx, d[i], a, rden);
+    __builtin_amdgcn_sched_barrier(0);   // (publish first: the scheduler would sink the two writes below the interior rows)
+    // the interior rows need nothing from other waves: they are computed while the edge rows travel
+    auto fix = [&](Row n, const Row &c, int i) {
         if (EDGE) {
             // fixed cells: pressureOut = 0 (Shaders:201-204), diffuse output = input (Shaders:91-94)
             const Row fixedv = OP == OP_PRESSURE ? Row{v2f{0.f, 0.f}, v2f{0.f, 0.f}} : c;
@@ -142,18 +169,34 @@ __device__ __forceinline__ void sweep_once(const Row (&src)[R], Row (&dst)[R], c
             if (fx3) n.b.y = fixedv.b.y;
             if ((rowfixed >> i) & 1u) n = fixedv;
         }
-        dst[i] = n;
-    }
+        return n;
+    };
+#pragma unroll
+    for (int i = 1; i < R - 1; ++i) dst[i] = fix(sweep_row<OP>(src[i], src[i - 1], src[i + 1], d[i], a, rden), src[i], i);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    const Row above = row_of(xch[buf][wup][1][lane]);    // row above this wave's strip
+    const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
+    dst[0] = fix(sweep_row<OP>(src[0], above, R > 1 ? src[1] : below, d[0], a, rden), src[0], 0);
+    if (R > 1) dst[R - 1] = fix(sweep_row<OP>(src[R - 1], src[R - 2], below, d[R - 1], a, rden), src[R - 1], R - 1);
 }
 
 // T sweeps on the register tile.  Diffuse: two per trip, ping-ponging between p and a second register tile q.
+// After sweep s only the tile rows [s, TH - s) are still exact, and only they feed the cells that are stored.  A
+// wave whose rows have all dropped out of that range (the outermost waves of the tile: 2 x 7 + 2 x 3 of the 160
+// wave-sweeps of a depth-10 launch on the 4 x 16 tile) stops sweeping, leaves its edge rows of the last iterate in
+// the exchange array and returns false: it stores nothing, and the caller ends it.  Its neighbour keeps reading
+// those rows -- from then on stale values that only reach rows which are out of range themselves.  (s_barrier counts the waves of the workgroup that are still
+// running, so the others do not wait for it.)
 template <int OP, int R, int NW, bool EDGE>
-__device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], float4 (*xch)[NW][2][64], int T,
+__device__ __forceinline__ bool run_sweeps_tile(Row (&p)[R], const Row (&d)[R], float4 (*xch)[NW][2][64], int Tall,
                                                 int lane, int wave, unsigned rowfixed, bool fx0, bool fx1, bool fx2,
                                                 bool fx3, float a, double rden)
 {
     const int wup = wave > 0 ? wave - 1 : 0;            // tile rim rows have no neighbour: any value, never used
     const int wdn = wave < NW - 1 ? wave + 1 : NW - 1;
+    const int useful = R * (wave < NW - 1 - wave ? wave : NW - 1 - wave) + R - 1;   // sweeps after which no row of this wave is in range
+    const int T = Tall < useful ? Tall : useful;
     int s = 0;
     if (OP == OP_DIFFUSE) {
         Row q[R];
@@ -189,6 +232,12 @@ __device__ __forceinline__ void run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
             prev = c;
         }
     }
+    if (T == Tall) return true;
+    // last words: the neighbours' next sweep still reads this wave's edge rows of the iterate just computed
+    xch[T & 1][wave][0][lane] = f4_of(p[0]);
+    xch[T & 1][wave][1][lane] = f4_of(p[R - 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows are in LDS before the wave ends
+    return false;
 }
 
 // MINW = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
@@ -211,6 +260,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     const GK g = A.g;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FS_TL(0);
     // De-phase the workgroups that share a CU.  All workgroups of the first dispatch wave start together
     // and would all load, then all sweep, then all store: HBM idles while the VALUs run and vice versa.
     // Holding back every other resident workgroup by about one load phase lets one workgroup of a CU
@@ -252,6 +302,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     // block-uniform: does this tile touch a fixed column or row at all?
     const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1 || ry0 <= 0 || ry0 + TH >= g.H - 1;
 
+#ifdef FS_PROBE
+    {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (threadIdx.x == blockDim.x / 2 && lin < FS_TL_MAX) {
+            g_timeline[8 * lin + 6] = edge_tile ? 1 : 0;
+            g_timeline[8 * lin + 7] = tile.x | (tile.y << 16);
+        }
+    }
+#endif
     Row p[R];
     Row d[R];
     unsigned rowfixed = 0;  // bit i: row i is a boundary row or outside the domain (wave-uniform)
@@ -313,6 +372,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         }
     }
 
+#ifdef FS_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0's own loads: the stamp is "tile loaded" for that wave)
+    FS_TL(1);
+#endif
+    bool alive;
 #ifdef FS_PROBE   // timing probes (scripts/jacobi_loops.py --probe): no sweeps / three times the sweeps / every tile through the edge path
     const int Trun = (A.stagger_mode & 16) ? 0 : (A.stagger_mode & 64) ? 3 * A.T : A.T;
     if (edge_tile || (A.stagger_mode & 128))
@@ -320,9 +384,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     const int Trun = A.T;
     if (edge_tile)
 #endif
-        run_sweeps_tile<OP, R, NW, true>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
+        alive = run_sweeps_tile<OP, R, NW, true>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
     else
-        run_sweeps_tile<OP, R, NW, false>(p, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
+        alive = run_sweeps_tile<OP, R, NW, false>(p, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
+    if (!alive) return;   // (before the epilogue's barrier: a wave that ends is no longer waited for)
+    FS_TL(2);
 
     // store the exact inner region
     const bool col_out = 4 * lane >= A.HX && 4 * lane < TW - A.HX && col_in_buf;
@@ -373,6 +439,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
             for (int s = 32; s > 0; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s));
             if (lane == 0 && vmax > 0.0f) atomicMax(A.cfl, __float_as_uint(vmax));
         }
+        FS_TL(3);
         return;
     }
     if (col_out) {
@@ -383,6 +450,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
             if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + gx, f4_of(p[i]));
         }
     }
+    FS_TL(3);
 }
 
 // tuning knobs (JacobiTuning, common.h: a process-wide default and a copy per context)
@@ -390,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 // fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
 // Tile: 4 rows per lane x 16 waves (64 VGPRs, 8 waves per SIMD).  The sweeps are bound by VALU issue and by
 // the per-sweep barrier, and twice the waves hide both better than the larger register tiles do.
-static JacobiTuning g_tuning = {{10, 8}, {4, 4}, 0, 0};
+static JacobiTuning g_tuning = {{10, 8}, {4, 4}, 0, 0, 100};
 JacobiTuning &default_tuning() { return g_tuning; }
 
 template <int OP, int R, int NW, int MINW>
@@ -456,45 +524,77 @@ static int launch_block(const JacobiTuning &tn, const fs_grid *g, int yb, int ye
 // n sweeps ping-ponging a -> b -> a ...; launch j must leave rows [yb-rem, ye+rem) valid,
 // rem = sweeps still to come, clipped to the domain.
 // gu/gv != nullptr (pressure): the last launch also subtracts the gradient of the final iterate from them
+// One launch per step(), so that two chains (row bands, project_n_bands) can be enqueued side by side.
 template <int OP>
-static int run_sweeps(const JacobiTuning &tn, const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
-                      size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
-                      float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr,
-                      float *cfl = nullptr)
-{
-    const int ex = gu ? 1 : 0;   // the gradient epilogue reads one more ring of the final iterate
-    const int need_lo = g->yb - n - ex > 0 ? g->yb - n - ex : 0;
-    const int need_hi = g->ye + n + ex < g->height ? g->ye + n + ex : g->height;
-    if (need_lo < g->y0 || need_hi > g->y0 + g->rows) {
-        set_error("jacobi: %d sweeps on rows [%d,%d) need rows [%d,%d) but the buffer holds [%d,%d)", n, g->yb,
-                  g->ye, need_lo, need_hi, g->y0, g->y0 + g->rows);
-        return FS_ERR_INVALID;
+struct SweepChain {
+    JacobiTuning tn;
+    fs_grid g;
+    const float *div;
+    float *src, *dst;
+    bool src_zero;
+    int nplanes;
+    size_t stride;
+    float ca, cden;
+    int rem, ex, launches = 0;
+    float *gu, *gv, *div_out, *cfl;
+    bool div_prologue;
+    hipStream_t stream;
+
+    SweepChain(const JacobiTuning &t, const fs_grid *grid, const float *div_, float *a, float *b, bool a_is_zero, int np, size_t str,
+               float ca_, float cden_, int n, hipStream_t st, float *gu_ = nullptr, float *gv_ = nullptr, bool pro = false,
+               float *div_out_ = nullptr, float *cfl_ = nullptr)
+        : tn(t), g(*grid), div(div_), src(a), dst(b), src_zero(a_is_zero), nplanes(np), stride(str), ca(ca_), cden(cden_), rem(n),
+          ex(gu_ ? 1 : 0), gu(gu_), gv(gv_), div_out(div_out_), cfl(cfl_), div_prologue(pro), stream(st) {}
+
+    // the rows of the input iterate (and of u, v, div) the whole chain reads must be in the buffer
+    int check(int n) const
+    {
+        const int need_lo = g.yb - n - ex > 0 ? g.yb - n - ex : 0;
+        const int need_hi = g.ye + n + ex < g.height ? g.ye + n + ex : g.height;
+        if (need_lo < g.y0 || need_hi > g.y0 + g.rows) {
+            set_error("jacobi: %d sweeps on rows [%d,%d) need rows [%d,%d) but the buffer holds [%d,%d)", n, g.yb, g.ye, need_lo,
+                      need_hi, g.y0, g.y0 + g.rows);
+            return FS_ERR_INVALID;
+        }
+        return FS_OK;
     }
-    const int maxT = tn.depth[OP];
-    int rem = n;
-    float *src = a, *dst = b;
-    bool src_zero = a_is_zero;
-    int launches = 0;
-    while (rem > 0) {
+    bool done() const { return rem <= 0; }
+    int step()
+    {
+        const int maxT = tn.depth[OP];
         const int T = rem < maxT ? rem : maxT;
         rem -= T;
         const int more = rem > 0 ? rem + ex : 0;
-        int yb = g->yb - more, ye = g->ye + more;
+        int yb = g.yb - more, ye = g.ye + more;
         if (yb < 0) yb = 0;
-        if (ye > g->height) ye = g->height;
+        if (ye > g.height) ye = g.height;
         const bool last = rem == 0, first = launches == 0;
         // first launch of a projection: the divergence is computed from gu/gv (still untouched: the epilogue only
         // runs in the last launch) and stored to div_out for the launches that follow
         const bool pro = div_prologue && first && !last;
-        int rc = launch_block<OP>(tn, g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
+        int rc = launch_block<OP>(tn, &g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
                                   last ? gu : nullptr, last ? gv : nullptr, stream, pro ? gu : nullptr, pro ? gv : nullptr,
                                   pro ? div_out : nullptr, last ? cfl : nullptr);
         if (rc) return rc;
         float *t = src; src = dst; dst = t;
         src_zero = false;
         ++launches;
+        return FS_OK;
     }
-    if (result_in_b) *result_in_b = launches & 1;
+};
+
+template <int OP>
+static int run_sweeps(const JacobiTuning &tn, const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
+                      size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
+                      float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr,
+                      float *cfl = nullptr)
+{
+    SweepChain<OP> ch(tn, g, div, a, b, a_is_zero, nplanes, stride, ca, cden, n, stream, gu, gv, div_prologue, div_out, cfl);
+    int rc = ch.check(n);
+    if (rc) return rc;
+    while (!ch.done())
+        if ((rc = ch.step())) return rc;
+    if (result_in_b) *result_in_b = ch.launches & 1;
     return FS_OK;
 }
 
@@ -525,6 +625,10 @@ int tuning_set(JacobiTuning &t, int key, int v)
         if (v < 0) return FS_ERR_INVALID;
         t.stagger = v;
         return FS_OK;
+    case FS_OPT_BAND_DELAY:
+        if (v < 0 || v > 100000) return FS_ERR_INVALID;   // at most 1 ms
+        t.band_delay = v;
+        return FS_OK;
     case FS_OPT_STAGGER_MODE:
 #ifndef FS_PROBE
         if (v > 3) return FS_ERR_INVALID;   // modes 0..3 choose which workgroups start late; higher bits exist in probe builds only
@@ -544,6 +648,7 @@ int tuning_get(const JacobiTuning &t, int key)
     case FS_OPT_TILE_VARIANT: return t.variant[0];
     case FS_OPT_TILE_VARIANT_DIFFUSE: return t.variant[1];
     case FS_OPT_STAGGER: return t.stagger;
+    case FS_OPT_BAND_DELAY: return t.band_delay;
     }
     return FS_ERR_INVALID;
 }
@@ -614,6 +719,67 @@ int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, f
                                    cfl_dev);
 }
 
+// One wave that sleeps: puts band B of a two-band projection out of step with band A (see project_n_bands).
+__global__ __launch_bounds__(64) void k_delay(int ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// The projection of a whole grid as TWO row bands, [yb, split) and [split, ye), each a chain of its own on its own
+// stream.  One chain leaves every launch with a partly filled last round of workgroups and a CU idles while its
+// workgroups load; two chains out of step fill each other's holes (3072^2: 142 -> ~122 us per 40 sweeps).  Each band
+// computes the rows beside the split redundantly, like a slab with deep ghost rows, so the bands never exchange:
+//   - band A ping-pongs pa/pb (the context's pressure planes), band B two private planes qa/qb: an intermediate
+//     iterate of one band is never overwritten under the other band's reads;
+//   - div is written by both first launches -- the same values where the bands overlap;
+//   - u, v: a band's LAST launch updates its own rows in place, the other band's FIRST launch reads rows on both
+//     sides of the split for the divergence: ev_first[x] (recorded after the first launch of band x) is waited for
+//     by the other band's last launch.
+// Result: rows [yb, split) of the final iterate in pa/pb (*result_in_b), rows [split, ye) in qa/qb (the same side).
+int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u, float *v, float *div, float *pa, float *pb,
+                    float *qa, float *qb, int n, int *result_in_b, void *stream_a, void *stream_b, void *ev_fork, void *ev_join,
+                    void *ev_first_a, void *ev_first_b)
+{
+    int rc = check_grid(g);
+    if (rc) return rc;
+    REQUIRE_FS("project_n_bands", u && v && div && pa && pb && qa && qb && pa != pb && qa != qb, "bad pointers");
+    REQUIRE_FS("project_n_bands", split > g->yb && split < g->ye, "split row outside the rows to compute");
+    REQUIRE_FS("project_n_bands", jacobi_launch_count(t, OP_PRESSURE, n) >= 2, "needs at least two launches");
+    REQUIRE_FS("project_n_bands", stream_a != stream_b && ev_fork && ev_join && ev_first_a && ev_first_b, "needs two streams and four events");
+    hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
+    fs_grid ga = *g, gb = *g;
+    ga.ye = split;
+    gb.yb = split;
+    SweepChain<OP_PRESSURE> A(t, &ga, div, pa, pb, true, 1, 0, 0.f, 1.f, n, sa, u, v, true, div);
+    SweepChain<OP_PRESSURE> B(t, &gb, div, qa, qb, true, 1, 0, 0.f, 1.f, n, sb, u, v, true, div);
+    if ((rc = A.check(n)) || (rc = B.check(n))) return rc;
+    FS_HIP(hipEventRecord((hipEvent_t)ev_fork, sa));
+    FS_HIP(hipStreamWaitEvent(sb, (hipEvent_t)ev_fork, 0));
+    int rca = FS_OK, rcb = FS_OK;
+    while (!A.done() && !rca && !rcb) {
+        if (A.rem <= t.depth[OP_PRESSURE]) {   // the last launches write u, v
+            FS_HIP(hipStreamWaitEvent(sa, (hipEvent_t)ev_first_b, 0));
+            FS_HIP(hipStreamWaitEvent(sb, (hipEvent_t)ev_first_a, 0));
+        }
+        const bool first = A.launches == 0;
+        // Two chains that start together stay in step -- every pair of launches ramps up and drains together, like
+        // one launch -- so band B starts a fraction of a launch late: from then on one chain is in full swing
+        // whenever the other drains and refills.
+        if (first && t.band_delay > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, sb, t.band_delay);
+        rca = A.step();
+        rcb = B.step();
+        if (first) {
+            FS_HIP(hipEventRecord((hipEvent_t)ev_first_a, sa));
+            FS_HIP(hipEventRecord((hipEvent_t)ev_first_b, sb));
+        }
+    }
+    FS_HIP(hipEventRecord((hipEvent_t)ev_join, sb));   // joined even after an error: a capture must end whole
+    FS_HIP(hipStreamWaitEvent(sa, (hipEvent_t)ev_join, 0));
+    if (result_in_b) *result_in_b = A.launches & 1;
+    return rca ? rca : rcb;
+}
+
 int diffuse_n(const JacobiTuning &t, const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
               float deltaTime, int n, int *result_in_b, void *stream)
 {
@@ -639,6 +805,16 @@ using namespace fs;
     } while (0)
 
 extern "C" {
+
+#ifdef FS_PROBE
+int fs_probe_timeline(unsigned long long *host, long nwords)   // probe build only: the last launch's g_timeline
+{
+    if (!host || nwords < 0 || nwords > 8L * FS_TL_MAX) return FS_ERR_INVALID;
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(fs::g_timeline), (size_t)nwords * sizeof(unsigned long long)));
+    return FS_OK;
+}
+#endif
 
 int fs_selftest_divide(float den, unsigned long long *mismatches_host)
 {

@@ -62,6 +62,20 @@ fs_grid grid_of(const fs_ctx *c, int depth)
     return fs_grid{c->W, c->H, c->pitch, c->b0, c->b1 - c->b0, yb, ye};
 }
 
+// Two bands pay when one launch of the loop leaves holes worth filling: a single GPU, the fused projection (the loop's
+// planes in the Infinity Cache), at least two launches, and enough tiles that each band still fills the chip once.
+bool bands_wanted(const fs_ctx *c)
+{
+    if (c->world > 1 || !c->split_rows || !c->stream2 || c->dry) return false;
+    const int N = c->params.solverIterations;
+    if (jacobi_launch_count(c->tuning, 0, N) < 2) return false;
+    const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
+    if (!(c->fuse >= 3 || (c->fuse == 1 && cache_resident))) return false;
+    const int T = std::min(c->tuning.depth[0], N), oh = std::max(8, 64 - 2 * T);   // (the default 256 x 64 tile)
+    const long tiles = (long)((c->W + 231) / 232) * (long)((c->H + oh - 1) / oh);
+    return tiles >= 768 && c->H >= 8 * (N + 2);
+}
+
 namespace {
 
 struct Planner {
@@ -195,7 +209,21 @@ struct Planner {
                 c->p_zero = false;
                 const float *div = c->f[F_DIV].p();
                 float *u = c->f[F_VEL].p(), *v = off(u, c->plane);
-                if (with_gradient) {
+                c->p_band_active = false;
+                if (with_gradient && bands_wanted(c) && c->p_band[0] && !lane) {
+                    float *dw = c->f[F_DIV].p(), *qa = c->p_band[0], *qb = c->p_band[1];
+                    hipStream_t st2 = c->stream2;
+                    hipEvent_t ef = c->ev_fork, ej = c->ev_join, ea = c->ev_band[0], eb = c->ev_band[1];
+                    const int split = (c->H / 2 + 3) & ~3;
+                    c->p_band_active = true;
+                    c->p_band_row = split;
+                    c->p_band_final = jacobi_launch_count(tn, 0, n) & 1;
+                    compute("project_n (2 bands)", g, n, [=]() {                      // Solver:522-547
+                        int ib = 0;
+                        return project_n_bands(tn, &g, split, u, v, dw, src, dst, qa, qb, n, &ib, st, st2, ef, ej, ea, eb);
+                    });
+                }
+                else if (with_gradient) {
                     float *dw = c->f[F_DIV].p();
                     compute("project_n", g, n, [=]() {                                // Solver:522-547
                         int ib = 0;
@@ -289,6 +317,7 @@ struct Planner {
         const Needs nd = chain_needs();
         const int need_p = nd.p, need_div = nd.div, need_v2 = nd.v2, need_v1 = nd.v1, need_v0 = nd.v0;
         Field &V = c->f[F_VEL];
+        c->p_band_active = false;
 
         if (multi && h_spec >= 0) ensure({{F_DYE, h_spec}}, SLOT_DYE, true);
         if (dye_diffusion_hoisted()) {                                                // :562-574, early and aside

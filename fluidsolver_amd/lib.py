@@ -21,7 +21,7 @@ FIELD_PLANES = {FIELD_VELOCITY: 2, FIELD_DENSITY: 3, FIELD_PRESSURE: 1, FIELD_DI
 DISPLAY_NONE, DISPLAY_DENSITY, DISPLAY_VELOCITY, DISPLAY_SPEED, DISPLAY_VORTICITY, DISPLAY_PARTICLES_ONLY = -1, 0, 1, 2, 3, 4
 OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES, OPT_TILE_VARIANT, OPT_FUSE = 0, 1, 2, 3, 4
 OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE, OPT_SLAB_OVERLAP = 5, 6, 7, 8, 9
-OPT_TILE_VARIANT_DIFFUSE, OPT_SLAB_PROFILE, OPT_SPLIT_PLANES = 10, 11, 12
+OPT_TILE_VARIANT_DIFFUSE, OPT_SLAB_PROFILE, OPT_SPLIT_PLANES, OPT_SPLIT_ROWS, OPT_BAND_DELAY = 10, 11, 12, 13, 14
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
  STAGE_FADE, STAGE_RENDER, STAGE_PRESSURE_CLEARED) = range(13)

@@ -272,6 +272,12 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_STAGGER = 7,        /* start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* which workgroups are held back, 0..3 (tuning) */
+       FS_OPT_BAND_DELAY = 14,    /* two-band projection: head start of the upper band, in 10 ns ticks (default 100; tuning) */
+       FS_OPT_SPLIT_ROWS = 13,    /* 1 (default): on one GPU, when the projection runs as one fused loop of at least two launches on a
+                                     grid of >= 768 tiles, the loop runs as two row bands on two streams, each computing the
+                                     rows beside the split redundantly (no exchange); the holes one chain of launches leaves
+                                     (partly filled last round, workgroups loading) are filled by the other; same bits;
+                                     0 = one chain */
        FS_OPT_SPLIT_PLANES = 12,  /* 1 (default): the independent planes of a diffuse loop run as two concurrent chains of
                                      launches (a second stream, fork/join by event; parallel branches of the frame's graph),
                                      so the partly filled last round of one launch is filled by the other chain, and the dye diffusion loop
@@ -370,6 +376,14 @@ int fs_set_particle_params(fs_ctx *ctx, const fs_particle_params *pp);
  *             fs_create_slab(W, H, device, comm, rank, -1, &ctx);
  *             per frame: fs_add_force(ctx, ...) with GLOBAL coordinates on EVERY rank; fs_step(ctx);
  *     fs_read_field / fs_write_field move the rows the slab owns ([plane][r1-r0][W]).
+ * COLLECTIVE on slabs -- every rank of the communicator must make the same call, in the same order, with the same
+ * scalar arguments, or the frame plans of the ranks (exchange depths, launch counts, ghost validity) diverge and the
+ * next fs_step deadlocks in a send/recv or computes on stale ghost rows:
+ *     fs_step, fs_add_force (global coordinates), fs_set_params, fs_set_option, fs_reset, fs_write_field (it marks the
+ *     ghost rows of that field stale on THIS rank; a neighbour that did not call it skips the refill), fs_particles_set,
+ *     fs_set_particle_params, fs_comm_selftest, fs_destroy/fs_comm_destroy (order only).
+ * Rank-local (any rank, any time): fs_read_field, fs_field_device_ptr, fs_particles_get/_count, fs_particle_lines,
+ * fs_slab_info/_stats/_waits, fs_sync, fs_last_error.  Single-GPU only: fs_stage, fs_particles_spawn.
  * RCCL is loaded at run time (FS_RCCL_LIBRARY if set, else a librccl already in the process, else the
  * default search path), so single-GPU hosts need none.
  * ---------------------------------------------------------------------- */

@@ -21,8 +21,9 @@ def timed(step, sync, warm, frames):
     t0 = time.perf_counter()
     for f in range(warm, warm + frames):
         step(f)
+    enq = (time.perf_counter() - t0) * 1e3 / frames     # host side only: the calls have returned
     sync()
-    return (time.perf_counter() - t0) * 1e3 / frames
+    return (time.perf_counter() - t0) * 1e3 / frames, enq
 
 
 def main():
@@ -39,9 +40,9 @@ def main():
                 pos, force, col = splat(W, H, f, ptr, K)
                 s.applyForce(pos, force, col)
             s.update()
-        t1 = timed(step1, s.sync, 10, frames)
+        t1, e1 = timed(step1, s.sync, 10, frames)
         s.close()
-        print("%dx%d single context            %8.3f ms/frame" % (W, H, t1), flush=True)
+        print("%dx%d single context            %8.3f ms/frame  host enqueue %6.1f us/frame" % (W, H, t1, e1 * 1e3), flush=True)
         for name, (asy, ovl) in (("blocking plain", (False, False)), ("async plain", (True, False)),
                                  ("blocking overlap", (False, True)), ("async overlap", (True, True))):
             g = LocalGroup(W, H, PARAMS, K, device=0, asynchronous=asy, overlap=ovl)
@@ -55,10 +56,10 @@ def main():
                     pos, force, col = splat(W, H, f, ptr, K)
                     g.add_force(pos, force, col)
                 g.update()
-            tk = timed(stepk, g.sync, 10, frames)
+            tk, ek = timed(stepk, g.sync, 10, frames)
             st = g.slabs[0].stats
-            print("%dx%d %d slabs %-17s %8.3f ms/frame  (+%5.1f%%)  halo %d rows, %.1f rounds/frame, %d re-plans"
-                  % (W, H, K, name, tk, 100 * (tk - t1) / t1, g.slabs[0].last_halo, st["exchanges"] / st["frames"], st["redo"]),
+            print("%dx%d %d slabs %-17s %8.3f ms/frame  (+%5.1f%%)  host enqueue %6.1f us/frame (all %d slabs from one thread), halo %d rows, %.1f rounds/frame, %d re-plans"
+                  % (W, H, K, name, tk, 100 * (tk - t1) / t1, ek * 1e3, K, g.slabs[0].last_halo, st["exchanges"] / st["frames"], st["redo"]),
                   flush=True)
             g.close()
 

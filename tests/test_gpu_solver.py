@@ -433,6 +433,41 @@ def test_diffuse_planes_as_two_chains_equal_one_chain(oracle_omp, W, H):
     assert np.array_equal(out[1][0], o.field(VELOCITY)) and np.array_equal(out[1][1], o.field(DENSITY))
 
 
+@pytest.mark.parametrize("N,depth", [(40, 10), (23, 10), (20, 7)])
+def test_projection_as_two_row_bands_equals_one_chain(oracle_omp, N, depth):
+    """FS_OPT_SPLIT_ROWS: the fused projection of a 3072 x 3072 frame as two row bands on two streams (band B in
+    private planes, its pressure rows copied home on read-back): eager frames and graph replays give the bits of the
+    one-chain loop and of the oracle, velocity, dye and pressure, for even and odd launch counts."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 3072
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, N)
+    out = []
+    for mode in (0, 1):
+        s = make_solver(W, H, params)
+        s.set_option(L.OPT_SPLIT_ROWS, mode)
+        s.set_option(L.OPT_BLOCK_DEPTH_PRESSURE, depth)
+        for f in range(6):
+            pos, force, col = splat(W, H, 4 * f + 2)
+            s.applyForce(pos, force, col)
+            s.update()
+            if f == 2:
+                mid_p = s.read_field(L.FIELD_PRESSURE)    # a read-back between frames (settles band B's rows)
+        out.append((s.read_field(L.FIELD_VELOCITY), s.read_field(L.FIELD_DENSITY), s.read_field(L.FIELD_PRESSURE), mid_p))
+        s.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(6):
+        pos, force, col = splat(W, H, 4 * f + 2)
+        o.add_force(pos, force, col, 5.0, 0.5)
+        o.update(p)
+    assert np.array_equal(out[1][0], o.field(VELOCITY)) and np.array_equal(out[1][1], o.field(DENSITY))
+    assert np.array_equal(out[1][2], o.field(PRESSURE))
+
+
 def test_config2_fifty_frames_match_oracle(oracle_omp):
     """BASELINE config 2 as bench.py runs it (3072^2, N = 40, one scripted splat per frame, hipGraph replay once
     the parameters have settled), 50 frames: velocity, dye and pressure bit-identical to the oracle at the end and
