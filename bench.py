@@ -154,6 +154,29 @@ def diffuse_microbench(s, W, H, sweeps=40, reps=10):
     return ms.value / launches, sweeps * reps / float(launches), ms.value / (reps * sweeps)
 
 
+def project_microbench(s, W, H, sweeps=40, reps=20):
+    """The projection of update() alone (Solver:522-547: divergence, clear, `sweeps` pressure sweeps, subtractGradient) the
+    way a frame runs it -- one loop of launches, as two row bands when FS_OPT_SPLIT_ROWS applies -- and as one chain,
+    on velocity ~ U(-1,1), HIP-event timed.  Returns {"us", "us_one_chain"} per projection."""
+    from fluidsolver_amd import lib as L
+    lib = L.load()
+    vel = np.empty((2, H, W), np.float32)
+    lib.fs_harness_fill_uniform(vel.ctypes.data_as(C.c_void_p), vel.size, -1.0, 1.0, 4321)
+    out = {}
+    ms = C.c_float()
+    for key, mode in (("us_one_chain", 0), ("us", 1)):
+        s.set_option(L.OPT_SPLIT_ROWS, mode)
+        s.write_field(L.FIELD_VELOCITY, vel)
+        s.stage(L.STAGE_PROJECT, sweeps)
+        s.sync()
+        L.check(lib.fs_timer_begin(s.ctx), s.ctx)
+        for _ in range(reps):
+            L.check(lib.fs_stage(s.ctx, L.STAGE_PROJECT, sweeps), s.ctx)
+        L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
+        out[key] = ms.value * 1e3 / reps
+    return out
+
+
 def cpu_baseline(W, H, params, budget_s=20.0, omp=False):
     """The scalar oracle ("port", 1 thread; omp=True: the same code with OpenMP over rows on the box's CPU share,
     bit-identical) on a bounded sample of the same workload: whole frames of the same scripted input, as many as
@@ -468,6 +491,22 @@ def main():
         if alg:
             out["frame_effective_GBps"] = alg * total_cells * fps / 1e9
             out["frame_frac_hbm_peak"] = out["frame_effective_GBps"] / HBM_PEAK_GBS
+        if params[5] >= 1:
+            # untimed A/B of the two-band projection where it matters, in the frame's graph (interleaved, 2 x 30 frames each)
+            ab, fa = {0: [], 1: []}, args.warmup + args.steps
+            for rep in range(2):
+                for mode in (0, 1):
+                    s.set_option(L.OPT_SPLIT_ROWS, mode)
+                    for f in range(fa, fa + 4):
+                        step(f)
+                    s.sync()
+                    t0 = time.perf_counter()
+                    for f in range(fa + 4, fa + 34):
+                        step(f)
+                    s.sync()
+                    ab[mode].append((time.perf_counter() - t0) / 30.0 * 1e6)
+                    fa += 34
+            s.set_option(L.OPT_SPLIT_ROWS, 1)
         ms_launch, sweeps_per_launch, ms_sweep = jacobi_microbench(s, W, H)
         achieved = ALG_BYTES_PRESSURE_SWEEP * total_cells * sweeps_per_launch / (ms_launch * 1e-3) / 1e9
         out["jacobi"] = {"gcell_updates_per_s_per_sweep": total_cells / (ms_sweep * 1e-3) / 1e9,
@@ -478,6 +517,14 @@ def main():
                                           "us_per_sweep": dsw * 1e3, "us_per_launch": dl * 1e3, "sweeps_per_launch": dspl,
                                           "effective_GBps": 16.0 * total_cells / (dsw * 1e-3) / 1e9,
                                           "note": "both velocity planes per sweep, 16 algorithmic B/cell/sweep"}
+        if params[5] >= 1:
+            pj = project_microbench(s, W, H, sweeps=params[5])
+            out["projection"] = {"sweeps": params[5], "frame_us_two_bands": sum(ab[1]) / 2, "frame_us_one_chain": sum(ab[0]) / 2,
+                                 "eager_stage_us_two_bands": pj["us"], "eager_stage_us_one_chain": pj["us_one_chain"],
+                                 "note": "Solver:522-547 (divergence, clear, sweeps, subtractGradient) as one loop of launches.  frame_us_*: whole "
+                                         "frames (graph replays) with the loop as two row bands out of step (FS_OPT_SPLIT_ROWS, default) / as one "
+                                         "chain, interleaved after the timed region.  eager_stage_us_*: the loop alone through FS_STAGE_PROJECT, "
+                                         "eager launches back to back -- there the fork/join events cost more than the bands gain"}
         # Contract fields: achieved = ALGORITHMIC bytes per launch / live launch time (the EFFECTIVE bandwidth: T
         # sweeps share one pass over memory, so it may exceed the HBM peak and is NOT a fraction of any hardware
         # limit).  The physical figures follow: hbm_frac (PMC bytes / live time / 8 TB/s) and valu_busy_frac.

@@ -67,6 +67,7 @@ static void drop_graphs(fs_ctx *c)
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graphs_after.clear();
+    c->graphs_epoch.clear();
 }
 
 static int nplanes_of(int field)
@@ -116,6 +117,38 @@ static int st_sweeps(fs_ctx *c, int fi, int n, bool pressure, bool p_is_zero)
         rc = fs::diffuse_n(c->tuning, &c->grid, F.p(), F.t(), F.np, c->plane, fi == F_VEL ? c->params.viscosity : c->params.diffusion,
                             c->params.deltaTime, n, &in_b, c->stream);                 // Solver:506-517, :563-573
     if (!rc && in_b) F.cur ^= 1;
+    return rc;
+}
+// band B of a two-band projection iterates in two private planes (allocated outside any capture)
+static void ensure_band_planes(fs_ctx *c, int N)
+{
+    if (c->p_band[0] || !fs::bands_wanted(c, N)) return;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipMalloc((void **)&c->p_band[i], c->plane * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(c->p_band[0]);
+            c->p_band[0] = c->p_band[1] = nullptr;   // the loop then stays one chain
+            break;
+        }
+    }
+}
+// Solver:522-547 the way a single-GPU frame runs them (FS_STAGE_PROJECT)
+static int st_project(fs_ctx *c, int n)
+{
+    if (n < 1) { fs::set_error("FS_STAGE_PROJECT needs at least one sweep"); return FS_ERR_INVALID; }
+    Field &P = c->f[F_P];
+    float *u = c->f[F_VEL].p(), *v = u + c->plane, *div = c->f[F_DIV].p();
+    int in_b = 0, rc;
+    ensure_band_planes(c, n);
+    if (fs::bands_wanted(c, n) && c->p_band[0]) {
+        const int split = (c->H / 2 + 3) & ~3;
+        rc = fs::project_n_bands(c->tuning, &c->grid, split, u, v, div, P.p(), P.t(), c->p_band[0], c->p_band[1], n, &in_b, c->stream,
+                                 c->stream2, c->ev_fork, c->ev_join, c->ev_band[0], c->ev_band[1]);
+        if (!rc) { c->p_band_dirty = true; c->p_band_row = split; c->p_band_final = in_b; }
+    } else
+        rc = fs::project_n_cfl(c->tuning, &c->grid, u, v, div, P.p(), P.t(), n, nullptr, &in_b, c->stream);
+    if (!rc && in_b) P.cur ^= 1;
     return rc;
 }
 static int st_advect(fs_ctx *c, int fi)
@@ -377,9 +410,17 @@ int fs_set_params(fs_ctx *c, const fs_params *p)
         return ctx_fail(c, FS_ERR_INVALID);
     }
     if (memcmp(&c->params, p, sizeof(*p)) != 0) {
+        // Scalars are baked into the recorded kernel nodes.  A change that can alter the PLAN (sweep counts, a stage
+        // switched on or off, the display mode) drops the graphs; a change of values only marks them stale, and the
+        // next fs_step refreshes the arguments of the instantiated graph in place (hipGraphExecUpdate).
+        const fs_params &o = c->params;
+        const bool same_plan = o.solverIterations == p->solverIterations && o.displayMode == p->displayMode &&
+                               (o.viscosity > 0.0f) == (p->viscosity > 0.0f) && (o.diffusion > 0.0f) == (p->diffusion > 0.0f) &&
+                               (o.vorticityStrength > 0.0f) == (p->vorticityStrength > 0.0f) && (o.fadeSpeed > 0.0f) == (p->fadeSpeed > 0.0f);
         c->params = *p;
         c->pparams.viscosity = p->viscosity;
-        drop_graphs(c);  // scalars are baked into the captured kernel nodes
+        if (same_plan && !c->graphs.empty()) c->param_epoch += 1;
+        else drop_graphs(c);
     }
     return FS_OK;
 }
@@ -449,18 +490,7 @@ int fs_step(fs_ctx *c)
         TRY(c, fs::run_frame(c));
         return FS_OK;
     }
-    // band B of a two-band projection iterates in two private planes (allocated here, outside any capture)
-    if (!c->p_band[0] && fs::bands_wanted(c)) {
-        for (int i = 0; i < 2; ++i) {
-            hipError_t e = hipMalloc((void **)&c->p_band[i], c->plane * sizeof(float));
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipFree(c->p_band[0]);
-                c->p_band[0] = c->p_band[1] = nullptr;   // the planner then keeps the loop in one chain
-                break;
-            }
-        }
-    }
+    ensure_band_planes(c, c->params.solverIterations);
     struct Mark { fs_ctx *c; ~Mark() { c->p_band_dirty = c->p_band_active; } } mark{c};   // after the frame, however it ran
     // Scalars are baked into the recorded kernel nodes, so a change of parameters invalidates the graphs.  A host
     // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
@@ -470,38 +500,66 @@ int fs_step(fs_ctx *c)
         c->stable_frames += 1;
         return FS_OK;
     }
+    // (from here on a change of values costs one host-side recording per ping-pong state and no instantiation)
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph
     // is keyed by the ping-pong state it was recorded from.
     const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3);
     auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
-        const unsigned long long before = pingpong_key(c);
-        hipGraph_t graph = nullptr;
-        TRYHIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        int rc = fs::run_frame(c);
-        hipError_t e = hipStreamEndCapture(c->stream, &graph);
-        if (rc || e != hipSuccess) {
-            if (graph) (void)hipGraphDestroy(graph);
-            set_pingpong(c, before);
-            if (rc) return ctx_fail(c, rc);
-            return ctx_fail(c, fs::hip_fail(e, "hipStreamEndCapture"));
+    if (it != c->graphs.end() && c->graphs_epoch[key] == c->param_epoch) {
+        TRYHIP(c, hipGraphLaunch(it->second, c->stream));
+        set_pingpong(c, c->graphs_after[key]);
+        c->stat_frames += 1;
+        return FS_OK;
+    }
+    // record the frame: a new graph for this ping-pong state, or new kernel arguments for the one that exists
+    const unsigned long long before = pingpong_key(c);
+    hipGraph_t graph = nullptr;
+    TRYHIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    int rc = fs::run_frame(c);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        set_pingpong(c, before);
+        if (rc) return ctx_fail(c, rc);
+        return ctx_fail(c, fs::hip_fail(e, "hipStreamEndCapture"));
+    }
+    hipGraphExec_t exec = it != c->graphs.end() ? it->second : nullptr;
+    if (exec) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+        if (hipGraphExecUpdate(exec, graph, &bad, &res) == hipSuccess && res == hipGraphExecUpdateSuccess)
+            c->stat_graph_updates += 1;
+        else {   // the plan changed after all (or the runtime cannot update this node): instantiate afresh
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(exec);
+            c->graphs.erase(key);
+            exec = nullptr;
         }
-        hipGraphExec_t exec = nullptr;
+    }
+    if (!exec) {
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
+            (void)hipGraphDestroy(graph);
             set_pingpong(c, before);
             return ctx_fail(c, fs::hip_fail(e, "hipGraphInstantiate"));
         }
-        // remember where the roles end up so replays can update them without re-recording
-        c->graphs[key] = exec;
-        c->graphs_after[key] = pingpong_key(c);
-        TRYHIP(c, hipGraphLaunch(exec, c->stream));
-        return FS_OK;
+        c->stat_graph_instantiations += 1;
     }
-    TRYHIP(c, hipGraphLaunch(it->second, c->stream));
-    set_pingpong(c, c->graphs_after[key]);
-    c->stat_frames += 1;
+    (void)hipGraphDestroy(graph);
+    // remember where the roles end up so replays can update them without re-recording
+    c->graphs[key] = exec;
+    c->graphs_after[key] = pingpong_key(c);
+    c->graphs_epoch[key] = c->param_epoch;
+    TRYHIP(c, hipGraphLaunch(exec, c->stream));
+    return FS_OK;
+}
+
+int fs_graph_stats(fs_ctx *c, long stats[3])
+{
+    if (!c || !stats) return FS_ERR_INVALID;
+    stats[0] = (long)c->graphs.size();
+    stats[1] = c->stat_graph_updates;
+    stats[2] = c->stat_graph_instantiations;
     return FS_OK;
 }
 
@@ -623,6 +681,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
     case FS_STAGE_FADE: rc = fs_k_fadeDensity(&c->grid, c->f[F_DYE].p(), 3, c->plane, c->params.fadeSpeed, c->stream); break;   // :587-591
     case FS_STAGE_RENDER: rc = st_render(c); break;
     case FS_STAGE_PRESSURE_CLEARED: rc = st_sweeps(c, F_P, n, true, true); break;                                  // :528-541
+    case FS_STAGE_PROJECT: rc = st_project(c, n); break;                                                             // :522-547
     default: fs::set_error("unknown stage %d", stage); rc = FS_ERR_INVALID;
     }
     return rc ? ctx_fail(c, rc) : FS_OK;

@@ -131,6 +131,9 @@ struct fs_ctx {
     std::vector<fs::Step> steps;
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
     std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
+    std::unordered_map<unsigned long long, unsigned long long> graphs_epoch;  // param_epoch the graph's kernel arguments are from
+    unsigned long long param_epoch = 0; // bumped when a scalar baked into the kernel nodes changes (fs_set_params)
+    long stat_graph_updates = 0, stat_graph_instantiations = 0;
     // statistics of the slab path
     long stat_exchanges = 0, stat_rows = 0, stat_frames = 0, stat_redo = 0;
     int last_halo = 0;
@@ -171,7 +174,7 @@ void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient 
 void plan_update_b(fs_ctx *c, int h);   // advection .. particles, with advection halo h
 int run_frame(fs_ctx *c);               // plan + execute one update() on this context (world 1 or RCCL)
 int run_frames(fs_ctx **cs, int n);     // ... on all n slabs of an in-process group, in lock step
-bool bands_wanted(const fs_ctx *c);     // will the planner project this context's frames in two row bands?
+bool bands_wanted(const fs_ctx *c, int N);   // is a projection of N sweeps on this context run as two row bands?
 
 }  // namespace fs
 

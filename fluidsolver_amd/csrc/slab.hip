@@ -64,10 +64,9 @@ fs_grid grid_of(const fs_ctx *c, int depth)
 
 // Two bands pay when one launch of the loop leaves holes worth filling: a single GPU, the fused projection (the loop's
 // planes in the Infinity Cache), at least two launches, and enough tiles that each band still fills the chip once.
-bool bands_wanted(const fs_ctx *c)
+bool bands_wanted(const fs_ctx *c, int N)
 {
     if (c->world > 1 || !c->split_rows || !c->stream2 || c->dry) return false;
-    const int N = c->params.solverIterations;
     if (jacobi_launch_count(c->tuning, 0, N) < 2) return false;
     const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
     if (!(c->fuse >= 3 || (c->fuse == 1 && cache_resident))) return false;
@@ -210,7 +209,7 @@ struct Planner {
                 const float *div = c->f[F_DIV].p();
                 float *u = c->f[F_VEL].p(), *v = off(u, c->plane);
                 c->p_band_active = false;
-                if (with_gradient && bands_wanted(c) && c->p_band[0] && !lane) {
+                if (with_gradient && bands_wanted(c, n) && c->p_band[0] && !lane) {
                     float *dw = c->f[F_DIV].p(), *qa = c->p_band[0], *qb = c->p_band[1];
                     hipStream_t st2 = c->stream2;
                     hipEvent_t ef = c->ev_fork, ej = c->ev_join, ea = c->ev_band[0], eb = c->ev_band[1];

@@ -24,7 +24,7 @@ OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE
 OPT_TILE_VARIANT_DIFFUSE, OPT_SLAB_PROFILE, OPT_SPLIT_PLANES, OPT_SPLIT_ROWS, OPT_BAND_DELAY = 10, 11, 12, 13, 14
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
- STAGE_FADE, STAGE_RENDER, STAGE_PRESSURE_CLEARED) = range(13)
+ STAGE_FADE, STAGE_RENDER, STAGE_PRESSURE_CLEARED, STAGE_PROJECT) = range(14)
 
 
 class FluidSolverError(RuntimeError):
@@ -97,6 +97,7 @@ SIGNATURES = {
     "fs_sync": (_i, [_p]),
     "fs_read_field": (_i, [_p, _i, _p, _sz]),
     "fs_write_field": (_i, [_p, _i, _p, _sz]),
+    "fs_graph_stats": (_i, [_p, C.POINTER(C.c_long)]),
     "fs_field_device_ptr": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i)]),
     "fs_stream": (_p, [_p]),
     "fs_timer_begin": (_i, [_p]),

@@ -327,7 +327,9 @@ int fs_timer_end(fs_ctx *ctx, float *ms);
 enum { FS_STAGE_VORTICITY = 0, FS_STAGE_APPLY_VORTICITY, FS_STAGE_DIFFUSE_VELOCITY, FS_STAGE_DIVERGENCE,
        FS_STAGE_CLEAR_PRESSURE, FS_STAGE_PRESSURE, FS_STAGE_SUBTRACT_GRADIENT, FS_STAGE_ADVECT_VELOCITY,
        FS_STAGE_DIFFUSE_DENSITY, FS_STAGE_ADVECT_DENSITY, FS_STAGE_FADE, FS_STAGE_RENDER,
-       FS_STAGE_PRESSURE_CLEARED /* clearTexture + the n sweeps exactly as update() runs them (clear folded in) */ };
+       FS_STAGE_PRESSURE_CLEARED, /* clearTexture + the n sweeps exactly as update() runs them (clear folded in) */
+       FS_STAGE_PROJECT /* Solver:522-547 as update() runs them on one GPU: divergence, clear, n sweeps, subtractGradient in one
+                           loop of launches (fs_k_project_n), as two row bands when FS_OPT_SPLIT_ROWS applies; n >= 1 */ };
 int fs_stage(fs_ctx *ctx, int stage, int n);
 
 /* Tracers (SoA on the device, owned by the context). */
@@ -422,6 +424,11 @@ int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a lo
  * overlap = the FS_OPT_SLAB_OVERLAP setting to plan for. */
 int fs_slab_plan_dump(int width, int height, int world, int rank, int ghost_rows, int overlap, const fs_params *p,
                       int frames, const int *halos, char *buf, size_t cap);
+
+/* The frame graphs of a single-GPU context: [0] graphs held (one per ping-pong state), [1] argument refreshes in place
+ * (hipGraphExecUpdate, after fs_set_params changed values only), [2] instantiations.  No reference counterpart
+ * (Metal encodes every frame anew, Solver:478-627). */
+int fs_graph_stats(fs_ctx *ctx, long stats[3]);
 
 const char *fs_last_error(fs_ctx *ctx); /* ctx may be NULL: last error of the calling thread */
 const char *fs_version(void);

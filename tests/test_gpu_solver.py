@@ -1,5 +1,6 @@
 """GPU parity of the whole step (fs_create / fs_add_force / fs_step ...) against the CPU oracle and the
 committed golden vectors, through the C ABI.  Bit-exact (see test_gpu_kernels.py for why)."""
+import ctypes as C
 import os
 import sys
 
@@ -293,6 +294,62 @@ def test_stage_calls_equal_update(oracle):
         b.stage(st, n)
     for f in (L.FIELD_VELOCITY, L.FIELD_DENSITY, L.FIELD_PRESSURE, L.FIELD_DIVERGENCE, L.FIELD_VORTICITY):
         assert np.array_equal(a.read_field(f), b.read_field(f))
+
+
+@pytest.mark.parametrize("W,H,N", [(120, 90, 9), (700, 330, 23), (3072, 3072, 40), (3072, 3072, 31)])
+def test_stage_project_equals_the_three_stages(W, H, N):
+    """FS_STAGE_PROJECT (divergence + clear + N sweeps + subtractGradient as one loop of launches; two row bands at
+    3072^2) == FS_STAGE_DIVERGENCE, FS_STAGE_PRESSURE_CLEARED, FS_STAGE_SUBTRACT_GRADIENT one after the other."""
+    from fluidsolver_amd import lib as L
+    lib = L.load()
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, N)
+    a, b = make_solver(W, H, params), make_solver(W, H, params)
+    vel = np.empty((2, H, W), np.float32)
+    lib.fs_harness_fill_uniform(vel.ctypes.data_as(C.c_void_p), vel.size, -1.0, 1.0, 99)
+    for rep in range(2):
+        for s in (a, b):
+            s.write_field(L.FIELD_VELOCITY, vel)
+        a.stage(L.STAGE_PROJECT, N)
+        for st, n in ((L.STAGE_DIVERGENCE, 0), (L.STAGE_PRESSURE_CLEARED, N), (L.STAGE_SUBTRACT_GRADIENT, 0)):
+            b.stage(st, n)
+        assert np.array_equal(a.read_field(L.FIELD_VELOCITY), b.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(a.read_field(L.FIELD_PRESSURE), b.read_field(L.FIELD_PRESSURE))
+        # the divergence plane of the fused loop is complete on the interior (the loop stores what its later launches read)
+        assert np.array_equal(a.read_field(L.FIELD_DIVERGENCE)[:, 1:-1, 1:-1], b.read_field(L.FIELD_DIVERGENCE)[:, 1:-1, 1:-1])
+        vel = a.read_field(L.FIELD_VELOCITY) * np.float32(1.5)
+    a.close(); b.close()
+
+
+def test_value_changes_refresh_the_graph_in_place(oracle):
+    """A host that moves a slider: viscosity, deltaTime, fade and vorticity strength change every few frames while the
+    frame graphs exist.  The plan is unchanged, so the instantiated graphs get new kernel arguments in place
+    (hipGraphExecUpdate) instead of being dropped and instantiated again -- and the fields still equal the oracle's."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    lib = L.load()
+    W, H, N = 300, 200, 12
+    base = (1.5e-4, 1e-5, 0.5, 10.0, 0.002, N)
+    s = make_solver(W, H, base)
+    o = oracle.solver(W, H)
+    seq = []
+    for f in range(24):
+        k = f // 3
+        p = (1.5e-4 * (1 + 0.1 * k), 1e-5, 0.5 + 0.01 * k, 10.0 + k, 0.002 + 0.0001 * k, N) if f >= 6 else base
+        seq.append(p)
+        (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = p
+        pos, force, col = splat(W, H, 5 * f)
+        s.applyForce(pos, force, col)
+        s.update()
+        o.add_force(pos, force, col, 5.0, p[2])
+        o.update(Params(*p))
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+        assert np.array_equal(s.read_field(fg), o.field(fo))
+    st = (C.c_long * 3)()
+    L.check(lib.fs_graph_stats(s.ctx, st), s.ctx)
+    assert st[0] >= 1 and st[1] >= 4, list(st)       # values changed 6 times with graphs in place
+    assert st[2] <= 8, list(st)                       # at most one instantiation per ping-pong state
+    s.close()
 
 
 def test_render_modes(oracle):
