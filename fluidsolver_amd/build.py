@@ -21,11 +21,12 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fP
 
 
 def source_sha():
-    """sha256 over the kernel sources, headers and build flags: what a profile under profiles/ was measured on.
-    bench.py prints PMC-derived figures only when this matches the tree it runs from."""
+    """sha256 over what the Jacobi kernels are compiled from (jacobi.hip, common.h, the build flags): what the PMC
+    profile under profiles/roofline_inputs.json was measured on.  bench.py prints PMC-derived figures only when this
+    matches the tree it runs from."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+    for path in sorted([os.path.join(CSRC, "jacobi.hip"), os.path.join(CSRC, "common.h")]):
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     h.update(" ".join(FLAGS[:6]).encode())
