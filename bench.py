@@ -450,6 +450,8 @@ def main():
     sync_all()
     barrier()
     sync_all()
+    if slabs:
+        s.host_times()     # reset the library's host-time accumulators
     t0 = time.perf_counter()
     for f in range(f0 + args.warmup, f0 + args.warmup + args.steps):
         step(f)
@@ -458,6 +460,7 @@ def main():
     barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
+    host_t = s.host_times() if slabs else None
     if slabs:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -568,13 +571,16 @@ def main():
         exposed = {"velocity_halo": float(wt[0]) * 1e3 / pf, "dye_halo": float(wt[1]) * 1e3 / pf,
                    "blocking_exchanges": float(wt[2]) * 1e3 / pf,
                    "note": "us per frame the kernels waited at joins (max over ranks, HIP events, 10 extra frames)"}
-        te = torch.tensor([t_enq], dtype=torch.float64)
+        te = torch.tensor([t_enq, host_t["step_us"] - host_t["wait_cfl_us"], host_t["wait_cfl_us"]], dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         out["slab"] = {"exposed_wait_us_per_frame": exposed, "check": slab_check,
-                       "host_enqueue_us_per_frame": float(te.item()) * 1e6 / args.steps,
-                       "host_enqueue_note": "wall time of the fs_add_force + fs_step calls of the timed frames on the slowest rank, before "
-                                            "any synchronisation (includes the host wait for the CFL all-reduce that sizes the advection "
-                                            "halo); the frame is host-bound when this approaches ms_per_step", "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+                       "host_calls_us_per_frame": float(te[0]) * 1e6 / args.steps,
+                       "host_enqueue_us_per_frame": float(te[1]), "host_wait_cfl_us_per_frame": float(te[2]),
+                       "host_enqueue_note": "max over ranks, timed frames.  host_calls = wall time of the fs_add_force + fs_step calls before any "
+                                            "synchronisation of the caller; inside fs_step (fs_slab_host_times) host_wait_cfl = blocked on the CFL "
+                                            "value that sizes the advection halo (one device round trip + all-reduce per frame: the host runs in "
+                                            "step with the GPU there), host_enqueue = the rest: planning and enqueueing ~25 launches and the "
+                                            "exchanges.  The frame is host-bound when host_enqueue approaches ms_per_step", "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
                        "overlap": bool(overlap), "advection_replans": st["redo"],

@@ -136,6 +136,8 @@ struct fs_ctx {
     long stat_graph_updates = 0, stat_graph_instantiations = 0;
     // statistics of the slab path
     long stat_exchanges = 0, stat_rows = 0, stat_frames = 0, stat_redo = 0;
+    double host_frame_us = 0.0, host_wait_us = 0.0;   // host time inside run_frames / of that blocked on the CFL value (fs_slab_host_times)
+    long host_frames = 0;
     int last_halo = 0;
     // tracers
     long max_particles = 0, n_particles = 0;

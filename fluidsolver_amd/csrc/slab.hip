@@ -39,6 +39,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -786,7 +787,11 @@ int cfl_phase(fs_ctx *c, int phase)
 int wait_cfl(fs_ctx *c)
 {
     fs_comm *cm = c->comm;
-    if (cm->kind != 0) FS_HIP(hipEventSynchronize(c->ev_cfl));
+    if (cm->kind != 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        FS_HIP(hipEventSynchronize(c->ev_cfl));
+        c->host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
     const int k = cm->kind == 1 ? 1 : cm->world;
     float m = 0.0f;
     for (int i = 0; i < k; ++i)
@@ -948,7 +953,16 @@ struct Saved {
 
 // One update() on n slabs (n = 1: this rank of an RCCL run, or a single GPU -- possibly under stream
 // capture, where nothing but kernel launches happens).
+static int run_frames_impl(fs_ctx **cs, int n);
 int run_frames(fs_ctx **cs, int n)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = run_frames_impl(cs, n);
+    cs[0]->host_frame_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    cs[0]->host_frames += 1;
+    return rc;
+}
+static int run_frames_impl(fs_ctx **cs, int n)
 {
     fs_ctx *c0 = cs[0];
     const bool multi = c0->world > 1;
@@ -1182,6 +1196,14 @@ int fs_slab_waits(fs_ctx *c, double wait_ms[3], long joins[3])
         wait_ms[i] = c->wait_ms[i]; joins[i] = c->wait_count[i];
         c->wait_ms[i] = 0.0; c->wait_count[i] = 0;
     }
+    return FS_OK;
+}
+
+int fs_slab_host_times(fs_ctx *c, double us[2], long *frames)
+{
+    if (!c || !us || !frames) return FS_ERR_INVALID;
+    us[0] = c->host_frame_us; us[1] = c->host_wait_us; *frames = c->host_frames;
+    c->host_frame_us = c->host_wait_us = 0.0; c->host_frames = 0;
     return FS_OK;
 }
 

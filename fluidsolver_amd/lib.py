@@ -97,6 +97,7 @@ SIGNATURES = {
     "fs_sync": (_i, [_p]),
     "fs_read_field": (_i, [_p, _i, _p, _sz]),
     "fs_write_field": (_i, [_p, _i, _p, _sz]),
+    "fs_slab_host_times": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "fs_graph_stats": (_i, [_p, C.POINTER(C.c_long)]),
     "fs_field_device_ptr": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i)]),
     "fs_stream": (_p, [_p]),

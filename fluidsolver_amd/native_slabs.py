@@ -116,6 +116,13 @@ class _Slab:
         L.check(self.lib.fs_slab_waits(self.ctx, ms, n), self.ctx)
         return {"vel_ms": ms[0], "dye_ms": ms[1], "blocking_ms": ms[2], "joins": [n[0], n[1], n[2]]}
 
+    def host_times(self):
+        """Since the last call: us per frame the host spent inside fs_step, and of that blocked on the CFL value."""
+        us, n = (C.c_double * 2)(), C.c_long()
+        L.check(self.lib.fs_slab_host_times(self.ctx, us, C.byref(n)), self.ctx)
+        k = max(1, n.value)
+        return {"step_us": us[0] / k, "wait_cfl_us": us[1] / k, "frames": n.value}
+
     # ---- tracers (SURVEY 8(f) rank 4): each lives on the rank that owns the row its lookup reads ----
     def particles_reserve(self, capacity, window=None, **params):
         """Room for `capacity` tracers on THIS rank; turns the tracer step of update() on.  params: fields of

@@ -418,6 +418,10 @@ int fs_slab_stats(fs_ctx *ctx, long stats[5]); /* exchange rounds, halo rows sen
 /* With FS_OPT_SLAB_PROFILE = 1: milliseconds this slab's kernels spent waiting for halo rows since the last call
  * -- [0] velocity halo, [1] dye halo, [2] blocking exchanges -- and how many waits were timed.  Blocks like fs_sync. */
 int fs_slab_waits(fs_ctx *ctx, double wait_ms[3], long joins[3]);
+/* Host time since the last call: us[0] = inside fs_step / fs_group_step on this context (planning, enqueueing, waiting),
+ * us[1] = the part of it blocked on the CFL value that sizes the advection halo (a device round trip + all-reduce per frame);
+ * us[0] - us[1] is what the host spends enqueueing.  frames = calls counted.  (A local group counts on its first slab.) */
+int fs_slab_host_times(fs_ctx *ctx, double us[2], long *frames);
 int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
 /* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
  * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f;
