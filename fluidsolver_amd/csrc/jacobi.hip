@@ -250,41 +250,16 @@ __device__ __forceinline__ bool run_sweeps_tile(Row (&p)[R], const Row (&d)[R], 
 // tile instead of loaded, and stored once per cell for the later launches: the separate divergence pass
 // (Solver:522-525) disappears.  The outermost ring of the tile gets a wrong divergence (its neighbours lie outside
 // the tile); that ring is invalid after the first sweep anyway and is never stored.
-template <int OP, int R, int NW, int MINW, bool EPI, bool PRO>
-__global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
+// Everything a workgroup does with its tile: load (or compute the divergence), T sweeps, store (or subtract the gradient).
+// EDGE = the tile touches a fixed (boundary / outside) row or column.  The two instantiations are separate bodies from
+// the first load on: the interior one carries no masks, no selects and none of their live ranges.
+template <int OP, int R, int NW, bool EPI, bool PRO, bool EDGE>
+__device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, float4 (*xch)[NW][2][64], const uint2 tile, const int lane,
+                                          const int wave, const int OW, const int OH)
 {
     constexpr int TW = 256;
     constexpr int TH = NW * R;
-    __shared__ float4 xch[2][NW][2][64];
-
-    const GK g = A.g;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FS_TL(0);
-    // De-phase the workgroups that share a CU.  All workgroups of the first dispatch wave start together
-    // and would all load, then all sweep, then all store: HBM idles while the VALUs run and vice versa.
-    // Holding back every other resident workgroup by about one load phase lets one workgroup of a CU
-    // stream its tile while the other sweeps.  Timing only: results do not depend on it (stagger modes 0..3).
-    if (A.stagger > 0) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        bool late;
-        switch (A.stagger_mode & 15) {
-        case 1: late = (lin & 1u) != 0 && lin < 512u; break;
-        case 2: late = ((lin >> 3) & 1u) != 0 && lin < 512u; break;
-        case 3: late = ((lin >> 8) & 1u) != 0; break;
-        default: late = ((lin >> 8) & 1u) != 0 && lin < 512u; break;
-        }
-        if (late) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < A.stagger) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    const int OW = TW - 2 * A.HX;
-    const int OH = TH - 2 * A.TE;
-    // Tile order.  Plain blockIdx by default; for a pressure loop whose three planes fit the Infinity Cache
-    // each XCD takes one contiguous chunk of the grid, so the overlapping tile rims hit in its L2 (3072^2:
-    // 143 -> 128 us per 40 sweeps; at 16384^2, HBM-bound, the same remap costs 4 %: eight distant streams).
-    const uint2 tile = A.xcd_chunked ? xcd_tile_chunked() : make_uint2(blockIdx.x, blockIdx.y);
+    (void)OW; (void)OH;
     const int x0 = tile.x * OW - A.HX;                   // tile column 0 (global), multiple of 4
     const int ry0 = A.yb + tile.y * OH - A.TE;           // tile row 0 (global)
     const int gx = x0 + 4 * lane;                        // this lane's first column
@@ -295,18 +270,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 
     const bool col_in_buf = gx >= 0 && gx < g.pitch;
     // fixed (never updated) columns of this lane: domain boundary columns and everything outside
-    const bool fx0 = (gx + 0) <= 0 || (gx + 0) >= g.W - 1;
-    const bool fx1 = (gx + 1) <= 0 || (gx + 1) >= g.W - 1;
-    const bool fx2 = (gx + 2) <= 0 || (gx + 2) >= g.W - 1;
-    const bool fx3 = (gx + 3) <= 0 || (gx + 3) >= g.W - 1;
-    // block-uniform: does this tile touch a fixed column or row at all?
-    const bool edge_tile = x0 <= 0 || x0 + TW >= g.W - 1 || ry0 <= 0 || ry0 + TH >= g.H - 1;
+    // (a tile that touches no fixed row or column -- EDGE false, the vast majority -- has none of these)
+    const bool fx0 = EDGE && ((gx + 0) <= 0 || (gx + 0) >= g.W - 1);
+    const bool fx1 = EDGE && ((gx + 1) <= 0 || (gx + 1) >= g.W - 1);
+    const bool fx2 = EDGE && ((gx + 2) <= 0 || (gx + 2) >= g.W - 1);
+    const bool fx3 = EDGE && ((gx + 3) <= 0 || (gx + 3) >= g.W - 1);
 
 #ifdef FS_PROBE
     {
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if (threadIdx.x == blockDim.x / 2 && lin < FS_TL_MAX) {
-            g_timeline[8 * lin + 6] = edge_tile ? 1 : 0;
+            g_timeline[8 * lin + 6] = EDGE ? 1 : 0;
             g_timeline[8 * lin + 7] = tile.x | (tile.y << 16);
         }
     }
@@ -318,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     for (int i = 0; i < R; ++i) {
         const int y = wy0 + i;
         const bool row_in_buf = y >= g.y0 && y < g.y0 + g.rows;
-        const bool rf = y <= 0 || y >= g.H - 1;
+        const bool rf = EDGE && (y <= 0 || y >= g.H - 1);
         rowfixed |= (rf ? 1u : 0u) << i;
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -377,16 +351,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
     FS_TL(1);
 #endif
     bool alive;
-#ifdef FS_PROBE   // timing probes (scripts/jacobi_loops.py --probe): no sweeps / three times the sweeps / every tile through the edge path
+#ifdef FS_PROBE   // timing probes (scripts/jacobi_loops.py --probe): no sweeps / three times the sweeps
     const int Trun = (A.stagger_mode & 16) ? 0 : (A.stagger_mode & 64) ? 3 * A.T : A.T;
-    if (edge_tile || (A.stagger_mode & 128))
 #else
     const int Trun = A.T;
-    if (edge_tile)
 #endif
-        alive = run_sweeps_tile<OP, R, NW, true>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
-    else
-        alive = run_sweeps_tile<OP, R, NW, false>(p, d, xch, Trun, lane, wave, 0u, false, false, false, false, A.a, A.rden);
+    alive = run_sweeps_tile<OP, R, NW, EDGE>(p, d, xch, Trun, lane, wave, rowfixed, fx0, fx1, fx2, fx3, A.a, A.rden);
     if (!alive) return;   // (before the epilogue's barrier: a wave that ends is no longer waited for)
     FS_TL(2);
 
@@ -451,6 +421,51 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
         }
     }
     FS_TL(3);
+}
+
+template <int OP, int R, int NW, int MINW, bool EPI, bool PRO>
+__global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
+{
+    constexpr int TW = 256;
+    constexpr int TH = NW * R;
+    __shared__ float4 xch[2][NW][2][64];
+
+    const GK g = A.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FS_TL(0);
+    // De-phase the workgroups that share a CU.  All workgroups of the first dispatch wave start together
+    // and would all load, then all sweep, then all store: HBM idles while the VALUs run and vice versa.
+    // Holding back every other resident workgroup by about one load phase lets one workgroup of a CU
+    // stream its tile while the other sweeps.  Timing only: results do not depend on it (stagger modes 0..3).
+    if (A.stagger > 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        bool late;
+        switch (A.stagger_mode & 15) {
+        case 1: late = (lin & 1u) != 0 && lin < 512u; break;
+        case 2: late = ((lin >> 3) & 1u) != 0 && lin < 512u; break;
+        case 3: late = ((lin >> 8) & 1u) != 0; break;
+        default: late = ((lin >> 8) & 1u) != 0 && lin < 512u; break;
+        }
+        if (late) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < A.stagger) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const int OW = TW - 2 * A.HX;
+    const int OH = TH - 2 * A.TE;
+    // Tile order.  Plain blockIdx by default; for a pressure loop whose three planes fit the Infinity Cache
+    // each XCD takes one contiguous chunk of the grid, so the overlapping tile rims hit in its L2 (3072^2:
+    // 143 -> 128 us per 40 sweeps; at 16384^2, HBM-bound, the same remap costs 4 %: eight distant streams).
+    const uint2 tile = A.xcd_chunked ? xcd_tile_chunked() : make_uint2(blockIdx.x, blockIdx.y);
+    const int x0t = tile.x * OW - A.HX, ry0t = A.yb + tile.y * OH - A.TE;
+    // block-uniform: does this tile touch a fixed column or row at all?
+    bool edge_tile = x0t <= 0 || x0t + TW >= g.W - 1 || ry0t <= 0 || ry0t + TH >= g.H - 1;
+#ifdef FS_PROBE
+    if (A.stagger_mode & 128) edge_tile = true;   // probe: every tile through the edge path
+#endif
+    if (edge_tile) tile_body<OP, R, NW, EPI, PRO, true>(A, g, xch, tile, lane, wave, OW, OH);
+    else tile_body<OP, R, NW, EPI, PRO, false>(A, g, xch, tile, lane, wave, OW, OH);
 }
 
 // tuning knobs (JacobiTuning, common.h: a process-wide default and a copy per context)
