@@ -68,6 +68,8 @@ fs_grid grid_of(const fs_ctx *c, int depth)
 bool bands_wanted(const fs_ctx *c, int N)
 {
     if (c->world > 1 || !c->split_rows || !c->stream2 || c->dry) return false;
+    // (launched eagerly the fork / join events cost more than the bands gain: frames that are never replayed keep one chain;
+    // FS_STAGE_PROJECT, a test and measurement hook, runs the bands either way)
     if (jacobi_launch_count(c->tuning, 0, N) < 2) return false;
     const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
     if (!(c->fuse >= 3 || (c->fuse == 1 && cache_resident))) return false;
@@ -210,7 +212,7 @@ struct Planner {
                 const float *div = c->f[F_DIV].p();
                 float *u = c->f[F_VEL].p(), *v = off(u, c->plane);
                 c->p_band_active = false;
-                if (with_gradient && bands_wanted(c, n) && c->p_band[0] && !lane) {
+                if (with_gradient && c->use_graph && bands_wanted(c, n) && c->p_band[0] && !lane) {
                     float *dw = c->f[F_DIV].p(), *qa = c->p_band[0], *qb = c->p_band[1];
                     hipStream_t st2 = c->stream2;
                     hipEvent_t ef = c->ev_fork, ej = c->ev_join, ea = c->ev_band[0], eb = c->ev_band[1];
