@@ -525,6 +525,32 @@ def test_projection_as_two_row_bands_equals_one_chain(oracle_omp, N, depth):
     assert np.array_equal(out[1][2], o.field(PRESSURE))
 
 
+def test_two_bands_beside_the_dye_side_chain(oracle_omp):
+    """All three streams of a context at once: the velocity planes as two diffuse chains, then the projection as two
+    row bands (streams 1 and 2), with the dye diffusion loop running beside them on the third stream -- eager frames
+    and replays equal the oracle."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 3072
+    params = (1.5e-4, 0.00002, 0.5, 10.0, 0.002, 20)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in range(6):
+        pos, force, col = splat(W, H, 7 * f + 3)
+        s.applyForce(pos, force, col)
+        s.update()
+        o.add_force(pos, force, col, 5.0, 0.5)
+        o.update(p)
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+        assert np.array_equal(s.read_field(fg), o.field(fo))
+    st = (C.c_long * 3)()
+    L.check(L.load().fs_graph_stats(s.ctx, st), s.ctx)
+    assert st[0] >= 1          # the later frames were replays
+    s.close()
+
+
 def test_config2_fifty_frames_match_oracle(oracle_omp):
     """BASELINE config 2 as bench.py runs it (3072^2, N = 40, one scripted splat per frame, hipGraph replay once
     the parameters have settled), 50 frames: velocity, dye and pressure bit-identical to the oracle at the end and
