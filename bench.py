@@ -492,8 +492,22 @@ def main():
     if not slabs:
         alg = ALG_BYTES_FRAME_CONFIG2 if params[5] == 40 else None
         if alg:
+            # algorithmic bytes per frame (per-sweep bytes x sweeps: the temporally blocked loops move them once per launch,
+            # so this is an EFFECTIVE rate and exceeds the peak) ...
             out["frame_effective_GBps"] = alg * total_cells * fps / 1e9
-            out["frame_frac_hbm_peak"] = out["frame_effective_GBps"] / HBM_PEAK_GBS
+            out["frame_effective_over_hbm_peak"] = out["frame_effective_GBps"] / HBM_PEAK_GBS
+            # ... and the physical one: PMC bytes of one frame (profiles/frame_traffic.json, scripts/frame_traffic.py) over the
+            # frame time measured here, withheld when any kernel source has changed since the PMC passes
+            try:
+                from fluidsolver_amd.build import source_sha_all
+                ft = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "frame_traffic.json")))
+                if ft.get("source_sha_all") == source_sha_all() and (W, H) == (3072, 3072) and not wl["particles"]:
+                    out["frame_traffic_bytes_pmc"] = ft["bytes_per_frame"]
+                    out["frame_hbm_frac"] = ft["bytes_per_frame"] / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                else:
+                    out["frame_traffic_withheld"] = "profiles/frame_traffic.json was measured on other sources or another workload"
+            except (OSError, ValueError, KeyError) as e:
+                out["frame_traffic_withheld"] = "%s: %s" % (type(e).__name__, e)
         if params[5] >= 1:
             # untimed A/B of the two-band projection where it matters, in the frame's graph (interleaved, 2 x 30 frames each)
             ab, fa = {0: [], 1: []}, args.warmup + args.steps

@@ -33,6 +33,17 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def source_sha_all():
+    """sha256 over every kernel source, the private headers and the build flags: what a whole-frame profile was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS[:2]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS[:6]).encode())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
