@@ -12,6 +12,7 @@
 // Shaders = fluidSolver/Shaders/FluidShaders.metal); the library is compiled with
 // -ffp-contract=off so no FMA is formed and results are bit-identical to the oracle.
 #include "common.h"
+#include <cstdlib>
 #include <math.h>
 #include <stdint.h>
 
@@ -211,6 +212,73 @@ __global__ __launch_bounds__(256) void k_vorticity_apply(GK g, int yb, int ye, c
     const size_t o = row_off(g, y) + x;
     st4(uo + o, uu);
     st4(vo + o, vv);
+}
+
+// The same fusion for planes that FIT the cache, where re-reading rows buys nothing and the two streaming kernels used to
+// win: a wave owns a 256-column strip (lane l: columns 4l..4l+3, the outermost lanes are halo) and MARCHES down K rows with
+// a rolling window in registers -- three rows of u, two of v, three of vorticity -- so every row of u and v is loaded once
+// per strip (+4 / +2 rows of run-in per K), the vorticity of a row is computed once, and its left / right neighbours
+// come from the neighbouring lanes by DPP.  Same expression per value (curl_at, vort_force): the same bits.
+template <int K, int XM>
+__global__ __launch_bounds__(256) void k_vorticity_apply_march(GK g, int yb, int ye, const float *__restrict__ u,
+                                                               const float *__restrict__ v, float *__restrict__ uo,
+                                                               float *__restrict__ vo, float strength, float dt)
+{
+    constexpr int OW = 248;                               // columns a strip stores: lanes 1..62
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (XM > 0: bands of XM block rows dealt to the XCDs in turn, see xcd_tile; the launch pads gridDim.y)
+    const uint2 t = XM > 0 ? xcd_tile<(XM > 0 ? XM : 1)>() : make_uint2(blockIdx.x, blockIdx.y);
+    const int x = (int)t.x * OW - 4 + 4 * lane;           // this lane's first column (multiple of 4)
+    const int y0 = yb + ((int)t.y * 4 + wave) * K;        // first row of this wave's chunk
+    if (y0 >= ye) return;
+    const bool in_buf = x >= 0 && x < g.pitch;
+    const bool stores = lane >= 1 && lane <= 62 && in_buf;
+    // Loads are unconditional (a lane outside the buffer reads the nearest quad inside it): no exec-mask branch between
+    // them, so the rows of the next step stay in flight under this step's arithmetic.  What such a lane holds reaches
+    // only boundary and padding cells, whose curl is 0 by definition and which get no force.
+    const int xc = x < 0 ? 0 : x > g.pitch - 4 ? g.pitch - 4 : x;
+    auto row = [&](const float *p, int r) { return ld4(p + row_off(g, clamp_row(g, r)) + xc); };
+    // vorticity of row r at this lane's four columns, from u(r-1), u(r+1), v(r)            Shaders:262-273
+    auto curl_row = [&](int r, const float4 &ut, const float4 &ub, const float4 &vc) {
+        const float vl = from_lane_below(vc.w), vr = from_lane_above(vc.x);
+        float4 w;
+        w.x = curl_at(g, x + 0, r, ub.x, ut.x, vc.y, vl);
+        w.y = curl_at(g, x + 1, r, ub.y, ut.y, vc.z, vc.x);
+        w.z = curl_at(g, x + 2, r, ub.z, ut.z, vc.w, vc.y);
+        w.w = curl_at(g, x + 3, r, ub.w, ut.w, vr, vc.z);
+        return w;
+    };
+    float4 u_m1 = row(u, y0 - 1), u_c = row(u, y0), u_p1 = row(u, y0 + 1);
+    float4 v_c = row(v, y0);
+    float4 wt, wc;
+    {
+        const float4 u_m2 = row(u, y0 - 2), v_m1 = row(v, y0 - 1);
+        wt = curl_row(y0 - 1, u_m2, u_c, v_m1);
+        wc = curl_row(y0, u_m1, u_p1, v_c);
+    }
+    // (rolled: unrolled with the next step's rows prefetched it needs 72 VGPRs and is slower, 36.5 vs 32 us at 3072^2)
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const int y = y0 + k;
+        if (y >= ye) break;
+        const float4 u_p2 = row(u, y + 2), v_p1 = row(v, y + 1);
+        const float4 wb = curl_row(y + 1, u_c, u_p2, v_p1);
+        const float wl = from_lane_below(wc.w), wr = from_lane_above(wc.x);
+        float4 uu = u_c, vv = v_c;
+        if (!is_boundary(g, x + 0, y)) vort_force(wl, wc.y, wt.x, wb.x, wc.x, strength, dt, uu.x, vv.x);
+        if (!is_boundary(g, x + 1, y)) vort_force(wc.x, wc.z, wt.y, wb.y, wc.y, strength, dt, uu.y, vv.y);
+        if (!is_boundary(g, x + 2, y)) vort_force(wc.y, wc.w, wt.z, wb.z, wc.z, strength, dt, uu.z, vv.z);
+        if (!is_boundary(g, x + 3, y)) vort_force(wc.z, wr, wt.w, wb.w, wc.w, strength, dt, uu.w, vv.w);
+        if (stores) {
+            const size_t o = row_off(g, y) + x;
+            st4(uo + o, uu);
+            st4(vo + o, vv);
+        }
+        wt = wc; wc = wb;
+        u_c = u_p1; u_p1 = u_p2;
+        v_c = v_p1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_apply_vorticity(GK g, int yb, int ye, const float *__restrict__ w,
@@ -843,6 +911,18 @@ int fs_k_vorticity_apply(const fs_grid *g, const float *u, const float *v, float
     REQUIRE(u && v && u_out && v_out, "null pointer");
     REQUIRE(u != u_out && v != v_out, "the confinement force needs the old velocity of the neighbours: not in place");
     EMPTY_OK(g);
+    if (g->width >= 512) {   // wide enough for 256-column strips: the marching form (32.1 vs 50.0 us at 3072^2, 918 vs 1234 us at 16384^2)
+        constexpr int K = 8;   // 5, 6, 8 rows per wave tie; 4 and 16 lose (run-in rows / too few waves)
+        unsigned gy = (g->ye - g->yb + 4 * K - 1) / (4 * K);
+        const int xm = gy >= 512u ? 8 : gy >= 32u ? 4 : 0;   // XCD bands of 8 / 4 block rows (profiles/r02_f_vorticity_march.log)
+        if (xm) gy = xcd_pad_rows(gy, xm);
+        const dim3 grid((g->width + 247) / 248, gy);
+        if (xm == 8) hipLaunchKernelGGL((k_vorticity_apply_march<K, 8>), grid, dim3(256), 0, STREAM, make_gk(g), g->yb, g->ye, u, v, u_out, v_out, strength, deltaTime);
+        else if (xm == 4) hipLaunchKernelGGL((k_vorticity_apply_march<K, 4>), grid, dim3(256), 0, STREAM, make_gk(g), g->yb, g->ye, u, v, u_out, v_out, strength, deltaTime);
+        else hipLaunchKernelGGL((k_vorticity_apply_march<K, 0>), grid, dim3(256), 0, STREAM, make_gk(g), g->yb, g->ye, u, v, u_out, v_out, strength, deltaTime);
+        FS_LAUNCH_CHECK("k_vorticity_apply_march");
+        return FS_OK;
+    }
     hipLaunchKernelGGL(k_vorticity_apply, quad_grid(g, 1), kBlock, 0, STREAM, make_gk(g), g->yb, g->ye, u, v, u_out, v_out,
                        strength, deltaTime);
     FS_LAUNCH_CHECK("k_vorticity_apply");

@@ -338,7 +338,8 @@ struct Planner {
             // out-of-cache planes: both passes in one, the vorticity plane never touches memory (it is then not
             // available to read back or display, so not in the vorticity display mode)
             const bool big = (double)c->pitch * (double)(c->H / c->world) * sizeof(float) >= 256.0 * 1024 * 1024;
-            if ((c->fuse == 4 || (c->fuse == 1 && big)) && p.displayMode != FS_DISPLAY_VORTICITY) {
+            // (the marching form of the fused pass wins at every size it applies to: grids at least 512 wide)
+            if ((c->fuse == 4 || (c->fuse == 1 && (big || c->W >= 512))) && p.displayMode != FS_DISPLAY_VORTICITY) {
                 const fs_grid g = grid_of(c, dv);
                 const float *u = V.p(), *v = off(u, plane);
                 float *uo = V.t(), *vo = off(uo, plane);

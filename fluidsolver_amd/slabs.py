@@ -376,7 +376,7 @@ class SlabSolver:
             dv = min(need_v1, dw - 1, eff("vel")) if multi else 0
             # out-of-cache planes: both passes in one, out of place, the vorticity plane never touches memory
             big = self.pitch * (self.H // self.world) * 4.0 >= 256.0 * 1024 * 1024
-            if big and hasattr(self.be, "vorticity_apply"):
+            if (big or self.W >= 512) and hasattr(self.be, "vorticity_apply"):   # (the marching form wins wherever it applies)
                 self.be.vorticity_apply(self.grid(dv), self.f["vel"], self.f["vel_t"],
                                         float(self.vorticityStrength), dt)     # :486-502
                 self.f["vel"], self.f["vel_t"] = self.f["vel_t"], self.f["vel"]

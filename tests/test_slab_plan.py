@@ -169,7 +169,7 @@ def test_overlap_plan_hides_both_rounds():
     assert f[6] == "join dye"
     assert f[7] == "advect_fade %d %d 3" % (r0, r0 + 7) and f[8] == "advect_fade %d %d 3" % (r1 - 7, r1)
     assert f[9] == "exchange_async dye:7"                       # frame 2 begins: dye halo under the chain
-    assert f[10].startswith("vorticity %d %d" % (r0 - 82, r1 + 82))   # (a 2048-row slab plane is 128 MiB: two passes)
+    assert f[10].startswith("vorticity_apply %d %d" % (r0 - 81, r1 + 81))   # curl + confinement in one marching pass (W >= 512)
     # one GPU, 16384^2: a plane (1 GiB) outgrows the Infinity Cache -> both advections in one pass
     one = NS.plan_dump(W, H, 1, 0, None, params, [0])
     assert "advect_both 0 16384 5\n" in one and "advect_fade" not in one
