@@ -256,6 +256,10 @@ typedef struct fs_params {
 enum { FS_DISPLAY_NONE = -1, FS_DISPLAY_DENSITY = 0, FS_DISPLAY_VELOCITY = 1, FS_DISPLAY_SPEED = 2,
        FS_DISPLAY_VORTICITY = 3, FS_DISPLAY_PARTICLES_ONLY = 4 };
 
+/* Intermediate planes are only as current as the frame plan keeps them: with FS_OPT_FUSE != 0 fs_step computes the
+ * vorticity in registers on grids at least 512 wide (FS_FIELD_VORTICITY is then not updated, except in the vorticity
+ * display mode), and the divergence of the domain's outermost ring may be skipped by the fused projection.  Velocity,
+ * density, pressure and display always hold the reference's values.  FS_OPT_FUSE = 0 or fs_stage keep every plane. */
 enum { FS_FIELD_VELOCITY = 0, FS_FIELD_DENSITY = 1, FS_FIELD_PRESSURE = 2,
        FS_FIELD_DIVERGENCE = 3, FS_FIELD_VORTICITY = 4, FS_FIELD_DISPLAY = 5 };
 
