@@ -469,11 +469,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 }
 
 // tuning knobs (JacobiTuning, common.h: a process-wide default and a copy per context)
-// From the 3072^2 sweeps in profiles/r01_tune_jacobi*.log.  Depths: the pressure sweep is cheap per cell, so
-// fewer passes over memory win (10); the diffuse sweep carries the division, so less halo recompute wins (8).
-// Tile: 4 rows per lane x 16 waves (64 VGPRs, 8 waves per SIMD).  The sweeps are bound by VALU issue and by
-// the per-sweep barrier, and twice the waves hide both better than the larger register tiles do.
-static JacobiTuning g_tuning = {{10, 8}, {4, 4}, 0, 0, 100};
+// Round 1 (profiles/r01_tune_jacobi*.log): depths 10 / 8 and the 4 x 16 tile (64 VGPRs, 8 waves per SIMD) for both loops.
+// Round 2, after the kernel was split into an edge and an interior body (profiles/r02_h_retune.log, interleaved A/Bs in the
+// frame): the pressure loop at depth 14 (three launches per 40 sweeps instead of four: -4 us per frame; the same per sweep
+// at 16384^2) and the diffuse loops on the 5 x 16 tile (256 x 80 cells, 56 VGPRs: 64 of 80 rows stored at depth 8 instead of
+// 48 of 64; -11 us per frame, -5 % per sweep at 16384^2).  The pressure loop stays on 4 x 16: with the divergence tile the
+// 5-row form spills.
+static JacobiTuning g_tuning = {{14, 8}, {4, 7}, 0, 0, 100};
 JacobiTuning &default_tuning() { return g_tuning; }
 
 template <int OP, int R, int NW, int MINW>

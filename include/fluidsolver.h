@@ -271,7 +271,7 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      the projection in one loop where each pays (size rules in DESIGN.md), both advections in one pass and
                                      curl + confinement in one pass for out-of-cache planes; 2 = fade only; 3 = projection loop only, at any size; 4 = every fusion at any
                                      size (tests); 0 = none */
-       FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* depth of the pressure loop, default 10 */
+       FS_OPT_BLOCK_DEPTH_PRESSURE = 5, /* depth of the pressure loop, default 14 */
        FS_OPT_BLOCK_DEPTH_DIFFUSE = 6,  /* depth of the diffuse loops, default 8 */
        FS_OPT_STAGGER = 7,        /* start delay (10 ns ticks) of every other resident
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
@@ -287,7 +287,7 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      so the partly filled last round of one launch is filled by the other chain, and the dye diffusion loop
                                      of a single-GPU frame runs beside the velocity chain (third stream); 0 = one chain */
        FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
-       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone */
+       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone (default 7: 5 rows per lane x 16 waves) */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
                                      depth); 0 = exchange, wait, compute */

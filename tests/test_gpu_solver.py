@@ -756,7 +756,7 @@ def test_jacobi_tuning_is_per_context():
     from fluidsolver_amd.script import splat
     lib = L.load()
     W, H = 700, 330
-    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 23)
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 29)
     a, b = FluidSolver(W, H), FluidSolver(W, H)
     try:
         for s in (a, b):
@@ -764,7 +764,7 @@ def test_jacobi_tuning_is_per_context():
             s.displayMode = None
         a.set_option(L.OPT_BLOCK_DEPTH, 3)
         a.set_option(L.OPT_TILE_VARIANT, 0)
-        assert lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE) == 10 and lib.fs_config_get(L.OPT_TILE_VARIANT) == 4
+        assert lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE) == 14 and lib.fs_config_get(L.OPT_TILE_VARIANT) == 4
         import ctypes as C
         from oracle_binding import full_grid   # noqa: F401  (plan dump needs no GPU; the launch counts show the depth in use)
         for f in range(3):
@@ -775,7 +775,7 @@ def test_jacobi_tuning_is_per_context():
         a.sync(); b.sync()
         for fld in (L.FIELD_VELOCITY, L.FIELD_DENSITY, L.FIELD_PRESSURE):
             assert np.array_equal(a.read_field(fld), b.read_field(fld))
-        # 23 sweeps: depth 3 -> 8 launches (even: result in the first buffer), depth 10 -> 3 launches (odd): the two contexts'
+        # 29 sweeps: depth 3 -> 10 launches (even: result in the first buffer), depth 14 -> 3 launches (odd): the two contexts'
         # pressure ping-pong sides differ after a frame, which only happens if each used its own depth
         pa, pb = C.c_void_p(), C.c_void_p()
         L.check(lib.fs_field_device_ptr(a.ctx, L.FIELD_PRESSURE, 0, C.byref(pa), None), a.ctx)
