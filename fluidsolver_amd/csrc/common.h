@@ -31,13 +31,13 @@ int jacobi_launch_count(const JacobiTuning &t, int op, int n);
 int pressure_n(const JacobiTuning &t, const fs_grid *g, const float *div, float *pa, float *pb, int n, int p_is_zero, int *result_in_b,
                void *stream);
 int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
-                  int *result_in_b, void *stream);
+                  int *result_in_b, void *stream, int cfl_reset);
 int diffuse_n(const JacobiTuning &t, const fs_grid *g, float *a, float *b, int nplanes, size_t plane_stride, float viscosity,
               float deltaTime, int n, int *result_in_b, void *stream);
 // the projection as two row bands on two streams (jacobi.hip); events are hipEvent_t
 int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u, float *v, float *div, float *pa, float *pb,
                     float *qa, float *qb, int n, int *result_in_b, void *stream_a, void *stream_b, void *ev_fork, void *ev_join,
-                    void *ev_first_a, void *ev_first_b);
+                    void *ev_first_a, void *ev_first_b, float *cfl_dev, int cfl_reset);
 
 void set_error(const char *fmt, ...);
 const char *get_error();
@@ -107,6 +107,15 @@ inline unsigned xcd_pad_rows(unsigned tile_rows, unsigned m) { return (tile_rows
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// max into a device word that thousands of waves share (the CFL bound of a slab): the value only grows, so a wave that
+// reads it first -- straight from L2; a stale, smaller reading merely costs the atomic it would have saved -- and finds
+// it already at least as large has nothing to add.  Without this every wave of a launch queues on one address (the
+// projection's last launch at 3072^2: 54 -> 88 us once the flow fills the grid).
+__device__ __forceinline__ void atomic_max_if_larger(unsigned *addr, unsigned bits)
+{
+    if (bits > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, bits);
+}
 
 // value of lane-1 / lane+1 of the wave (0 at the wave ends): one DPP operand, no LDS.
 __device__ __forceinline__ float from_lane_below(float x)  // lane i gets lane i-1

@@ -64,6 +64,7 @@ using namespace fs;
 static void drop_graphs(fs_ctx *c)
 {
     c->stable_frames = 0;
+    fs::drop_segment_graphs(c);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graphs_after.clear();
@@ -116,22 +117,8 @@ static int st_sweeps(fs_ctx *c, int fi, int n, bool pressure, bool p_is_zero)
     else
         rc = fs::diffuse_n(c->tuning, &c->grid, F.p(), F.t(), F.np, c->plane, fi == F_VEL ? c->params.viscosity : c->params.diffusion,
                             c->params.deltaTime, n, &in_b, c->stream);                 // Solver:506-517, :563-573
-    if (!rc && in_b) F.cur ^= 1;
+    if (!rc && in_b) F.flip();
     return rc;
-}
-// band B of a two-band projection iterates in two private planes (allocated outside any capture)
-static void ensure_band_planes(fs_ctx *c, int N)
-{
-    if (c->p_band[0] || !fs::bands_wanted(c, N)) return;
-    for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipMalloc((void **)&c->p_band[i], c->plane * sizeof(float));
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(c->p_band[0]);
-            c->p_band[0] = c->p_band[1] = nullptr;   // the loop then stays one chain
-            break;
-        }
-    }
 }
 // Solver:522-547 the way a single-GPU frame runs them (FS_STAGE_PROJECT)
 static int st_project(fs_ctx *c, int n)
@@ -140,15 +127,15 @@ static int st_project(fs_ctx *c, int n)
     Field &P = c->f[F_P];
     float *u = c->f[F_VEL].p(), *v = u + c->plane, *div = c->f[F_DIV].p();
     int in_b = 0, rc;
-    ensure_band_planes(c, n);
+    fs::ensure_band_planes(c, n);
     if (fs::bands_wanted(c, n) && c->p_band[0]) {
         const int split = (c->H / 2 + 3) & ~3;
         rc = fs::project_n_bands(c->tuning, &c->grid, split, u, v, div, P.p(), P.t(), c->p_band[0], c->p_band[1], n, &in_b, c->stream,
-                                 c->stream2, c->ev_fork, c->ev_join, c->ev_band[0], c->ev_band[1]);
+                                 c->stream2, c->ev_fork, c->ev_join, c->ev_band[0], c->ev_band[1], nullptr, 0);
         if (!rc) { c->p_band_dirty = true; c->p_band_row = split; c->p_band_final = in_b; }
     } else
-        rc = fs::project_n_cfl(c->tuning, &c->grid, u, v, div, P.p(), P.t(), n, nullptr, &in_b, c->stream);
-    if (!rc && in_b) P.cur ^= 1;
+        rc = fs::project_n_cfl(c->tuning, &c->grid, u, v, div, P.p(), P.t(), n, nullptr, &in_b, c->stream, 0);
+    if (!rc && in_b) P.flip();
     return rc;
 }
 static int st_advect(fs_ctx *c, int fi)
@@ -156,7 +143,7 @@ static int st_advect(fs_ctx *c, int fi)
     Field &F = c->f[fi];
     float *u = c->f[F_VEL].p(), *v = u + c->plane;
     int rc = fs_k_advect(&c->grid, u, v, F.p(), F.t(), F.np, c->plane, c->params.deltaTime, c->err_flag, c->stream);   // Solver:550-556, :577-582
-    if (!rc) F.cur ^= 1;                                                               // :558, :584
+    if (!rc) F.flip();                                                               // :558, :584
     return rc;
 }
 static int st_render(fs_ctx *c)
@@ -250,16 +237,17 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
     if (e != hipSuccess) rc = fs::hip_fail(e, "hipStreamCreate");
     for (int i = 0; i < 2; ++i) { alloc(&c->f[F_VEL].buf[i], 2); alloc(&c->f[F_DYE].buf[i], 3); alloc(&c->f[F_P].buf[i], 1); }
     alloc(&c->f[F_DIV].buf[0], 1); alloc(&c->f[F_VORT].buf[0], 1); alloc(&c->display, 4);
+    if (world > 1) alloc(&c->f[F_VEL].buf[2], 2);   // the spare of a slab's velocity (ctx.h)
     if (!rc) {
         e = hipMalloc((void **)&c->err_flag, sizeof(int));
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(err_flag)");
     }
     if (!rc) {
-        e = hipMalloc((void **)&c->cfl_dev, sizeof(float));
+        e = hipMalloc((void **)&c->cfl_dev, 2 * sizeof(float));
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(cfl)");
     }
     if (!rc) {
-        e = hipHostMalloc((void **)&c->cfl_host, (size_t)world * sizeof(float), hipHostMallocDefault);
+        e = hipHostMalloc((void **)&c->cfl_host, 2 * (size_t)world * sizeof(float), hipHostMallocDefault);
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipHostMalloc(cfl)");
     }
     if (!rc) {
@@ -279,7 +267,8 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         // the in-process groups and of a 2-rank run never complete on this runtime -- the tests hang -- so plain)
         e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cfl, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cfl[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cfl[1], hipEventDisableTiming);
         for (int i = 0; i < SLOT_COUNT && e == hipSuccess; ++i) {
             e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_slot[i], hipEventDisableTiming);
@@ -343,14 +332,15 @@ int fs_destroy(fs_ctx *c)
     if (!c) return FS_OK;
     if (c->dry) { delete c; return FS_OK; }
     (void)hipSetDevice(c->device);
+    (void)fs::settle(c);   // a halo check still owed: repair the last frame while the group is whole (no-op otherwise)
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     drop_graphs(c);
-    if (c->comm && c->comm->kind != 1 && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
+    if (c->comm && !c->comm->solo() && c->rank < (int)c->comm->members.size() && c->comm->members[c->rank] == c)
         c->comm->members[c->rank] = nullptr;
-    for (int i = 0; i < F_COUNT; ++i) { (void)hipFree(c->f[i].buf[0]); (void)hipFree(c->f[i].buf[1]); }
+    for (int i = 0; i < F_COUNT; ++i) { (void)hipFree(c->f[i].buf[0]); (void)hipFree(c->f[i].buf[1]); (void)hipFree(c->f[i].buf[2]); }
     (void)hipFree(c->display); (void)hipFree(c->err_flag); (void)hipFree(c->cfl_dev);
     if (c->cfl_host) (void)hipHostFree(c->cfl_host);
     for (int i = 0; i < 7; ++i) { (void)hipFree(c->part[i]); (void)hipFree(c->part_t[i]); (void)hipFree(c->outbox[i]); }
@@ -372,7 +362,12 @@ int fs_destroy(fs_ctx *c)
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
-    if (c->ev_cfl) (void)hipEventDestroy(c->ev_cfl);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_cfl[i]) (void)hipEventDestroy(c->ev_cfl[i]);
+    if (c->ev_serial) {
+        if (c->comm && c->comm->last_serial == c->ev_serial) c->comm->last_serial = nullptr;
+        (void)hipEventDestroy(c->ev_serial);
+    }
     for (int i = 0; i < SLOT_COUNT; ++i) {
         if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
         if (c->ev_slot[i]) (void)hipEventDestroy(c->ev_slot[i]);
@@ -388,9 +383,10 @@ int fs_destroy(fs_ctx *c)
 int fs_reset(fs_ctx *c)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     const size_t pb = c->plane * sizeof(float);
     for (int i = 0; i < F_COUNT; ++i) {
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 3; ++k)
             if (c->f[i].buf[k]) TRYHIP(c, hipMemsetAsync(c->f[i].buf[k], 0, c->f[i].np * pb, c->stream));
         c->f[i].valid = kInf;   // an all-zero field is valid at any ghost depth
     }
@@ -404,6 +400,7 @@ int fs_reset(fs_ctx *c)
 int fs_set_params(fs_ctx *c, const fs_params *p)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (!p) { fs::set_error("params is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
     if (p->solverIterations < 0 || p->solverIterations > 100000) {
         fs::set_error("solverIterations %d out of range", p->solverIterations);
@@ -435,22 +432,34 @@ int fs_get_params(fs_ctx *c, fs_params *p)
 int fs_set_option(fs_ctx *c, int option, int value)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
+    auto set = [](int &field, int v) { const bool changed = field != v; field = v; return changed; };
+    bool changed = true;
     switch (option) {
-    case FS_OPT_USE_GRAPH: c->use_graph = value ? 1 : 0; break;
+    case FS_OPT_USE_GRAPH: changed = set(c->use_graph, value ? 1 : 0); break;
     case FS_OPT_BLOCK_DEPTH: case FS_OPT_BLOCK_DEPTH_PRESSURE: case FS_OPT_BLOCK_DEPTH_DIFFUSE:
     case FS_OPT_TILE_VARIANT: case FS_OPT_TILE_VARIANT_DIFFUSE: case FS_OPT_STAGGER: case FS_OPT_STAGGER_MODE: case FS_OPT_BAND_DELAY:
         // this context's own copy: another context in the process keeps its tuning (fs_config_set changes the default)
         if (fs::tuning_set(c->tuning, option, value)) { fs::set_error("option %d: value %d out of range", option, value); return ctx_fail(c, FS_ERR_INVALID); }
         break;
-    case FS_OPT_WITH_PARTICLES: c->with_particles = value ? 1 : 0; break;
-    case FS_OPT_FUSE: c->fuse = (value >= 0 && value <= 4) ? value : 1; break;
-    case FS_OPT_SLAB_OVERLAP: c->overlap = value ? 1 : 0; break;
-    case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; break;
-    case FS_OPT_SPLIT_PLANES: c->split_planes = value ? 1 : 0; break;
-    case FS_OPT_SPLIT_ROWS: c->split_rows = value ? 1 : 0; break;
+    case FS_OPT_WITH_PARTICLES: changed = set(c->with_particles, value ? 1 : 0); break;
+    case FS_OPT_FUSE: changed = set(c->fuse, (value >= 0 && value <= 4) ? value : 1); break;
+    case FS_OPT_SLAB_OVERLAP: changed = set(c->overlap, value ? 1 : 0); break;
+    case FS_OPT_SLAB_PROFILE: c->profile = value ? 1 : 0; changed = false; break;        // (joins are never part of a recorded segment)
+    case FS_OPT_SLAB_DEFER: c->defer_check = value ? 1 : 0; changed = false; break;
+    case FS_OPT_SEGMENT_GRAPH_AFTER: c->seg_min_stable = value < 0 ? 0 : value; changed = false; break;
+    case FS_OPT_SLAB_SERIALIZE:
+        if (!c->comm || c->comm->solo()) { fs::set_error("FS_OPT_SLAB_SERIALIZE is a measurement aid of local groups"); return ctx_fail(c, FS_ERR_STATE); }
+        if (value && !c->ev_serial) TRYHIP(c, hipEventCreateWithFlags(&c->ev_serial, hipEventDisableTiming));
+        c->comm->serialize = value ? 1 : 0;
+        c->comm->last_serial = nullptr;
+        changed = false;
+        break;
+    case FS_OPT_SPLIT_PLANES: changed = set(c->split_planes, value ? 1 : 0); break;
+    case FS_OPT_SPLIT_ROWS: changed = set(c->split_rows, value ? 1 : 0); break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
-    drop_graphs(c);
+    if (changed) drop_graphs(c);   // (a value that is already in force keeps the recorded frames)
     return FS_OK;
 }
 
@@ -461,6 +470,9 @@ int fs_add_force(fs_ctx *c, float pos_x, float pos_y, float force_x, float force
 {
     CTX(c);
     if (!color_rgba) { fs::set_error("color is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
+    // a slab whose last frame still owes its halo check: remember the splat, the repair has to repeat it (slab.hip)
+    if (c->chk_pending)
+        c->splat_log.push_back(fs_ctx::Splat{pos_x, pos_y, force_x, force_y, color_rgba[0], color_rgba[1], color_rgba[2], radius, deltaTime});
     const fs_grid g = fs::grid_of(c, c->G);
     float *u = c->f[F_VEL].p(), *v = u + c->plane;
     float *d = c->f[F_DYE].p();
@@ -476,21 +488,23 @@ static unsigned long long pingpong_key(const fs_ctx *c)
 }
 static void set_pingpong(fs_ctx *c, unsigned long long k)
 {
-    c->f[F_VEL].cur = (int)(k & 1); c->f[F_DYE].cur = (int)((k >> 1) & 1); c->f[F_P].cur = (int)((k >> 2) & 1);
+    const int cur[3] = {(int)(k & 1), (int)((k >> 1) & 1), (int)((k >> 2) & 1)};
+    fs::Field *fl[3] = {&c->f[F_VEL], &c->f[F_DYE], &c->f[F_P]};
+    for (int i = 0; i < 3; ++i) { fl[i]->cur = cur[i]; fl[i]->oth = cur[i] ^ 1; }   // (one GPU: the roles never rotate)
 }
 
 int fs_step(fs_ctx *c)
 {
     CTX(c);
     if (c->world > 1) {
-        if (!c->comm || c->comm->kind != 1) {
+        if (!c->comm || !c->comm->solo()) {
             fs::set_error("fs_step: a slab of an in-process group is stepped by fs_group_step");
             return ctx_fail(c, FS_ERR_STATE);
         }
         TRY(c, fs::run_frame(c));
         return FS_OK;
     }
-    ensure_band_planes(c, c->params.solverIterations);
+    fs::ensure_band_planes(c, c->params.solverIterations);
     struct Mark { fs_ctx *c; ~Mark() { c->p_band_dirty = c->p_band_active; } } mark{c};   // after the frame, however it ran
     // Scalars are baked into the recorded kernel nodes, so a change of parameters invalidates the graphs.  A host
     // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
@@ -566,6 +580,7 @@ int fs_graph_stats(fs_ctx *c, long stats[3])
 int fs_sync(fs_ctx *c)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (c->xstream) TRYHIP(c, hipStreamSynchronize(c->xstream));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     int flag = 0;
@@ -584,7 +599,7 @@ static int settle_pressure(fs_ctx *c)
 {
     if (!c->p_band_dirty) return FS_OK;
     c->p_band_dirty = false;
-    const size_t o = (size_t)c->p_band_row * c->pitch, n = (size_t)(c->H - c->p_band_row) * c->pitch;
+    const size_t o = (size_t)(c->p_band_row - c->b0) * c->pitch, n = (size_t)(c->r1 - c->p_band_row) * c->pitch;
     TRYHIP(c, hipMemcpyAsync(c->f[F_P].p() + o, c->p_band[c->p_band_final] + o, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return FS_OK;
 }
@@ -617,18 +632,21 @@ static int copy_field(fs_ctx *c, int field, float *host, size_t bytes, bool to_h
 int fs_read_field(fs_ctx *c, int field, float *host, size_t bytes)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     return copy_field(c, field, host, bytes, true, "fs_read_field");
 }
 
 int fs_write_field(fs_ctx *c, int field, const float *host, size_t bytes)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     return copy_field(c, field, const_cast<float *>(host), bytes, false, "fs_write_field");
 }
 
 int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pitch)
 {
     if (!c || !dev_ptr) return FS_ERR_INVALID;
+    TRY(c, fs::settle(c));
     const int np = nplanes_of(field);
     if (plane < 0 || plane >= np) { fs::set_error("bad field/plane %d/%d", field, plane); return ctx_fail(c, FS_ERR_INVALID); }
     if (field == FS_FIELD_PRESSURE) TRY(c, settle_pressure(c));
@@ -660,6 +678,7 @@ int fs_timer_end(fs_ctx *c, float *ms)
 int fs_stage(fs_ctx *c, int stage, int n)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     SINGLE(c, "fs_stage");
     if (n < 0) { fs::set_error("negative sweep count"); return ctx_fail(c, FS_ERR_INVALID); }
     TRY(c, settle_pressure(c));
@@ -690,6 +709,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
 int fs_particles_reserve(fs_ctx *c, long capacity)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (capacity < 0) { fs::set_error("negative tracer capacity"); return ctx_fail(c, FS_ERR_INVALID); }
     TRYHIP(c, hipStreamSynchronize(c->stream));
     const bool slab = c->world > 1;
@@ -721,6 +741,7 @@ int fs_particles_reserve(fs_ctx *c, long capacity)
 int fs_set_particle_params(fs_ctx *c, const fs_particle_params *pp)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (!pp) { fs::set_error("particle params is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
     if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
     return FS_OK;
@@ -732,6 +753,7 @@ int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const 
                      const float *life, const float *mass, const float *age)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (n < 0) { fs::set_error("negative particle count"); return ctx_fail(c, FS_ERR_INVALID); }
     const long lo = c->world > 1 ? (long)((__int128)n * c->rank / c->world) : 0;
     const long hi = c->world > 1 ? (long)((__int128)n * (c->rank + 1) / c->world) : n;
@@ -752,6 +774,7 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
                      float *age)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (n < 0 || n > c->n_particles) { fs::set_error("asked for %ld of %ld particles", n, c->n_particles); return ctx_fail(c, FS_ERR_INVALID); }
     float *dst[7] = {px, py, vx, vy, life, mass, age};
     TRYHIP(c, hipStreamSynchronize(c->stream));
@@ -805,6 +828,7 @@ int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, un
 int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     const long n = c->n_particles;
     if (n == 0) return FS_OK;
     if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
@@ -828,6 +852,7 @@ int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particl
 int fs_particle_lines_static(fs_ctx *c, float viewportW, float viewportH, float particleScale, float *host_xy4, float *host_alpha)
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     const long n = c->n_particles;
     if (n == 0) return FS_OK;
     if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines_static: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }

@@ -17,13 +17,18 @@ constexpr int kInf = 1 << 30;
 // A field and its ping-pong partner (the reference swaps texture references, Solver:516,:540,:558,
 // :572,:584).  `valid` = how many ghost rows beside the owned rows still equal the neighbour's
 // owned rows (kInf: everywhere, e.g. an all-zero field).
+// The velocity of a slab has a THIRD buffer (spr): a frame that speculates on its advection halo is checked only after
+// the next frame's stencil chain has been enqueued, and until then the velocity its advection read must survive, so
+// that chain writes into the spare instead (rotate(), see run_frames in slab.hip).
 struct Field {
-    float *buf[2] = {nullptr, nullptr};
-    int cur = 0;
+    float *buf[3] = {nullptr, nullptr, nullptr};
+    int cur = 0, oth = 1, spr = 2;
     int np = 1;
     int valid = kInf;
     float *p() const { return buf[cur]; }
-    float *t() const { return buf[cur ^ 1]; }
+    float *t() const { return buf[oth]; }
+    void flip() { const int k = cur; cur = oth; oth = k; }
+    void rotate() { if (buf[spr]) { const int k = oth; oth = spr; spr = k; } }
 };
 
 struct Xfer {
@@ -62,13 +67,21 @@ inline T *off(T *p, size_t n) { return p ? p + n : p; }
 // possible transport); kind 2 copies asynchronously on the exchange streams, ordered only by the
 // same events the RCCL path uses, so the K slabs really run concurrently and a missing dependency
 // shows up as a wrong result.
+// kind 3 = loopback, a measurement aid: ONE rank of a `world`-rank run whose peers do not exist.  Every transfer is a device
+// copy of the same size out of the slab's own rows, the CFL reduction returns the slab's own bound: the fields are
+// meaningless, but the slab runs the plan, the launches, the copies and the host work of a real rank, alone on its GPU.
 struct fs_comm {
     int kind = 0;
     int world = 1;
-    int rank = 0;                       // RCCL only
+    int rank = 0;                       // RCCL, loopback
     int device = 0;                     // RCCL only
     void *nccl = nullptr;               // ncclComm_t
     std::vector<fs_ctx *> members;      // local group: index = rank
+    bool solo() const { return kind == 1 || kind == 3; }   // one rank per communicator object (stepped by fs_step)
+    // measurement only (FS_OPT_SLAB_SERIALIZE, local groups): the kernels of the K slabs, which share one GPU here, run one
+    // slab after the other instead of side by side -- K x the time one slab's frame takes on a GPU of its own
+    int serialize = 0;
+    hipEvent_t last_serial = nullptr;   // end of the launches most recently enqueued by any member
 };
 
 struct fs_ctx {
@@ -86,16 +99,20 @@ struct fs_ctx {
     fs::Field f[fs::F_COUNT];
     float *display = nullptr;           // 4 planes
     int *err_flag = nullptr;            // device
-    float *cfl_dev = nullptr;           // device: max |v_y| of the owned rows
-    float *cfl_host = nullptr;          // pinned, `world` floats (RCCL uses the first)
+    // CFL bound, two slots used by alternate frames (the host reads frame f's value while frame f + 1 already reduces its own)
+    int cfl_slot = 0;
+    float *cfl_dev = nullptr;           // device, 2 floats: max |v_y| of the owned rows
+    float *cfl_host = nullptr;          // pinned, 2 x `world` floats (RCCL uses the first of each slot)
     float cfl_max = 0.0f;               // all-reduced value of the current frame
     // exchange stream: every halo transfer and the CFL reduction run here, next to the kernels
     hipStream_t xstream = nullptr;
     hipEvent_t ev_main = nullptr;       // main stream: "rows are final" (what a transfer waits for)
+    bool ev_main_fresh = false;         // ... and nothing has been enqueued on the main stream since it was last recorded
     hipEvent_t ev_copied[fs::SLOT_COUNT] = {nullptr, nullptr, nullptr};   // kind 2: my receives are done
     hipEvent_t ev_slot[fs::SLOT_COUNT] = {nullptr, nullptr, nullptr};     // transfer complete (sends and receives)
     bool pending[fs::SLOT_COUNT] = {false, false, false};
-    hipEvent_t ev_cfl = nullptr;        // CFL value has landed in cfl_host
+    hipEvent_t ev_cfl[2] = {nullptr, nullptr};   // CFL value of the slot has landed in cfl_host
+    hipEvent_t ev_serial = nullptr;     // FS_OPT_SLAB_SERIALIZE: my launches so far are done
     int overlap = 1;                    // FS_OPT_SLAB_OVERLAP: speculative halo + split advection
     // FS_OPT_SLAB_PROFILE: timed event pairs around every join, so a run can report how long the kernels really
     // waited for halo rows (the part of the traffic that was NOT hidden)
@@ -134,8 +151,26 @@ struct fs_ctx {
     std::unordered_map<unsigned long long, unsigned long long> graphs_epoch;  // param_epoch the graph's kernel arguments are from
     unsigned long long param_epoch = 0; // bumped when a scalar baked into the kernel nodes changes (fs_set_params)
     long stat_graph_updates = 0, stat_graph_instantiations = 0;
+    // Slab frames (world > 1): the exchange-free runs of kernel launches of a plan ("segments") are recorded as hipGraphs
+    // and replayed, keyed by everything that decides their launches (ping-pong roles at plan start, the steps' row
+    // ranges and sweep counts, the scalar parameters); exchanges, joins and the CFL reduction stay eager between them.
+    std::unordered_map<unsigned long long, hipGraphExec_t> seg_graphs;
+    unsigned long long plan_salt = 0;   // set by run_frames before a plan is executed: which plan, from which roles
+    long stat_seg_replays = 0, stat_seg_captures = 0, stat_seg_eager = 0;
+    int seg_min_stable = 2;             // frames the parameters must have stayed put before segments are recorded
+    // The speculated advection halo of frame f is checked against the all-reduced CFL bound only at the next call that
+    // is not fs_add_force (fs_step of frame f + 1, fs_sync, a read ...): the host does not wait for the GPU inside
+    // fs_step.  Until then the roles from before the advection are kept, and the splats applied since are logged, so
+    // that a guess that was too small can be repaired: advection planned again with the true depth, splats re-applied.
+    int defer_check = 1;                // FS_OPT_SLAB_DEFER
+    bool chk_pending = false;
+    int chk_h = 0, chk_slot = 0;
+    fs::Field chk_saved[fs::F_COUNT];
+    struct Splat { float px, py, fx, fy, r, g, b, radius, dt; };
+    std::vector<Splat> splat_log;
     // statistics of the slab path
     long stat_exchanges = 0, stat_rows = 0, stat_frames = 0, stat_redo = 0;
+    double host_part_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // fs_slab_host_breakdown: planning, replays, recordings, eager runs, exchanges, CFL reduction, joins, tracers
     double host_frame_us = 0.0, host_wait_us = 0.0;   // host time inside run_frames / of that blocked on the CFL value (fs_slab_host_times)
     long host_frames = 0;
     int last_halo = 0;
@@ -176,7 +211,10 @@ void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient 
 void plan_update_b(fs_ctx *c, int h);   // advection .. particles, with advection halo h
 int run_frame(fs_ctx *c);               // plan + execute one update() on this context (world 1 or RCCL)
 int run_frames(fs_ctx **cs, int n);     // ... on all n slabs of an in-process group, in lock step
-bool bands_wanted(const fs_ctx *c, int N);   // is a projection of N sweeps on this context run as two row bands?
+int settle(fs_ctx *c);                  // the deferred halo check of the last frame, if one is pending (this rank, or the whole local group)
+void drop_segment_graphs(fs_ctx *c);
+bool bands_wanted(const fs_ctx *c, int N);
+void ensure_band_planes(fs_ctx *c, int N);   // is a projection of N sweeps on this context run as two row bands?
 
 }  // namespace fs
 

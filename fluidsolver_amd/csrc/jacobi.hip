@@ -66,6 +66,7 @@ struct JacobiArgs {
     const float *du, *dv;   // divergence prologue (PRO): velocity planes the divergence is computed from ...
     float *div_out;         // ... and the plane it is stored to (for the later launches of the loop)
     unsigned *cfl;          // EPI on a slab: max |v| of the updated v plane over the stored rows (atomicMax), or null
+    unsigned *cfl_zero;     // PRO on a slab: word to clear (the bound the loop's LAST launch accumulates into), or null
     float a, den;      // diffuse: a = dt*visc*W*H, den = 1 + 4a
     double rden;       // RN64(1 / den)
     int xcd_chunked;   // tile order, see the kernel
@@ -310,6 +311,9 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
         d[i] = row_of(dv);
     }
     if (PRO) {
+        // (a slab's frame: the CFL bound starts from 0 -- every launch with the epilogue, which accumulates into it, is
+        // ordered behind every launch with the prologue, so no separate clear has to be enqueued)
+        if (A.cfl_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *A.cfl_zero = 0u;
         // v of the rows above / below this wave's strip through the edge-row exchange (buffer 1: the sweeps start
         // with buffer 0), u's left / right neighbours by DPP
         const int wup = wave > 0 ? wave - 1 : 0, wdn = wave < NW - 1 ? wave + 1 : NW - 1;
@@ -407,7 +411,7 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
         }
         if (A.cfl) {   // one atomicMax per wave (non-negative floats order like their bit patterns)
             for (int s = 32; s > 0; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s));
-            if (lane == 0 && vmax > 0.0f) atomicMax(A.cfl, __float_as_uint(vmax));
+            if (lane == 0 && vmax > 0.0f) atomic_max_if_larger(A.cfl, __float_as_uint(vmax));
         }
         FS_TL(3);
         return;
@@ -500,7 +504,8 @@ static int launch_variant(const JacobiArgs &A0, const fs_grid *g, int nplanes, h
 template <int OP>
 static int launch_block(const JacobiTuning &tn, const fs_grid *g, int yb, int ye, const float *in, float *out, const float *div,
                         int nplanes, size_t stride, int T, float a, float den, float *gu, float *gv, hipStream_t stream,
-                        const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr, float *cfl = nullptr)
+                        const float *du = nullptr, const float *dv = nullptr, float *div_out = nullptr, float *cfl = nullptr,
+                        float *cfl_zero = nullptr)
 {
     JacobiArgs A;
     A.g = make_gk(g);
@@ -517,6 +522,7 @@ static int launch_block(const JacobiTuning &tn, const fs_grid *g, int yb, int ye
     A.dv = dv;
     A.div_out = div_out;
     A.cfl = reinterpret_cast<unsigned *>(cfl);
+    A.cfl_zero = reinterpret_cast<unsigned *>(cfl_zero);
     A.TE = T + (gu ? 1 : 0);
     A.HX = (A.TE + 3) & ~3;
     A.a = a;
@@ -554,7 +560,7 @@ struct SweepChain {
     float ca, cden;
     int rem, ex, launches = 0;
     float *gu, *gv, *div_out, *cfl;
-    bool div_prologue;
+    bool div_prologue, cfl_reset = false;   // cfl_reset: the first launch (which must then be a prologue launch) clears *cfl
     hipStream_t stream;
 
     SweepChain(const JacobiTuning &t, const fs_grid *grid, const float *div_, float *a, float *b, bool a_is_zero, int np, size_t str,
@@ -591,7 +597,7 @@ struct SweepChain {
         const bool pro = div_prologue && first && !last;
         int rc = launch_block<OP>(tn, &g, yb, ye, src_zero ? nullptr : src, dst, div, nplanes, stride, T, ca, cden,
                                   last ? gu : nullptr, last ? gv : nullptr, stream, pro ? gu : nullptr, pro ? gv : nullptr,
-                                  pro ? div_out : nullptr, last ? cfl : nullptr);
+                                  pro ? div_out : nullptr, last ? cfl : nullptr, pro && cfl_reset ? cfl : nullptr);
         if (rc) return rc;
         float *t = src; src = dst; dst = t;
         src_zero = false;
@@ -604,9 +610,10 @@ template <int OP>
 static int run_sweeps(const JacobiTuning &tn, const fs_grid *g, const float *div, float *a, float *b, bool a_is_zero, int nplanes,
                       size_t stride, float ca, float cden, int n, int *result_in_b, hipStream_t stream,
                       float *gu = nullptr, float *gv = nullptr, bool div_prologue = false, float *div_out = nullptr,
-                      float *cfl = nullptr)
+                      float *cfl = nullptr, bool cfl_reset = false)
 {
     SweepChain<OP> ch(tn, g, div, a, b, a_is_zero, nplanes, stride, ca, cden, n, stream, gu, gv, div_prologue, div_out, cfl);
+    ch.cfl_reset = cfl_reset;
     int rc = ch.check(n);
     if (rc) return rc;
     while (!ch.done())
@@ -714,14 +721,17 @@ int pressure_n(const JacobiTuning &t, const fs_grid *g, const float *div, float 
     return run_sweeps<OP_PRESSURE>(t, g, div, pa, pb, p_is_zero != 0, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream);
 }
 
+// cfl_reset: *cfl_dev starts from 0 (cleared by the loop's first launch; by a memset when the loop is a single launch)
 int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
-                  int *result_in_b, void *stream)
+                  int *result_in_b, void *stream, int cfl_reset)
 {
     int rc = check_grid(g);
     if (rc) return rc;
     REQUIRE_FS("fs_k_project_n", u && v && div && pa && pb && pa != pb, "bad pointers");
     REQUIRE_FS("fs_k_project_n", n >= 1, "needs at least one sweep");
     if (result_in_b) *result_in_b = 0;
+    if (cfl_reset && cfl_dev && (g->ye <= g->yb || jacobi_launch_count(t, OP_PRESSURE, n) < 2))
+        FS_HIP(hipMemsetAsync(cfl_dev, 0, sizeof(float), (hipStream_t)stream));
     if (g->ye <= g->yb) return FS_OK;
     if (jacobi_launch_count(t, OP_PRESSURE, n) < 2) {
         // a single launch cannot hold both ends (its epilogue would write velocity another tile's prologue reads):
@@ -733,7 +743,7 @@ int project_n_cfl(const JacobiTuning &t, const fs_grid *g, float *u, float *v, f
         if (rc) return rc;
     }
     return run_sweeps<OP_PRESSURE>(t, g, div, pa, pb, true, 1, 0, 0.f, 1.f, n, result_in_b, (hipStream_t)stream, u, v, true, div,
-                                   cfl_dev);
+                                   cfl_dev, cfl_reset != 0);
 }
 
 // One wave that sleeps: puts band B of a two-band projection out of step with band A (see project_n_bands).
@@ -756,7 +766,7 @@ __global__ __launch_bounds__(64) void k_delay(int ticks)
 // Result: rows [yb, split) of the final iterate in pa/pb (*result_in_b), rows [split, ye) in qa/qb (the same side).
 int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u, float *v, float *div, float *pa, float *pb,
                     float *qa, float *qb, int n, int *result_in_b, void *stream_a, void *stream_b, void *ev_fork, void *ev_join,
-                    void *ev_first_a, void *ev_first_b)
+                    void *ev_first_a, void *ev_first_b, float *cfl_dev, int cfl_reset)
 {
     int rc = check_grid(g);
     if (rc) return rc;
@@ -768,8 +778,11 @@ int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u
     fs_grid ga = *g, gb = *g;
     ga.ye = split;
     gb.yb = split;
-    SweepChain<OP_PRESSURE> A(t, &ga, div, pa, pb, true, 1, 0, 0.f, 1.f, n, sa, u, v, true, div);
-    SweepChain<OP_PRESSURE> B(t, &gb, div, qa, qb, true, 1, 0, 0.f, 1.f, n, sb, u, v, true, div);
+    // (cfl_dev, slabs: both bands' last launches fold max |v| of their rows into it; cfl_reset: band A's first launch
+    // clears it -- both last launches wait for both first ones, ev_first_*)
+    SweepChain<OP_PRESSURE> A(t, &ga, div, pa, pb, true, 1, 0, 0.f, 1.f, n, sa, u, v, true, div, cfl_dev);
+    SweepChain<OP_PRESSURE> B(t, &gb, div, qa, qb, true, 1, 0, 0.f, 1.f, n, sb, u, v, true, div, cfl_dev);
+    A.cfl_reset = cfl_reset != 0 && cfl_dev;
     if ((rc = A.check(n)) || (rc = B.check(n))) return rc;
     FS_HIP(hipEventRecord((hipEvent_t)ev_fork, sa));
     FS_HIP(hipStreamWaitEvent(sb, (hipEvent_t)ev_fork, 0));
@@ -869,13 +882,13 @@ int fs_k_pressureSolve_n_gradient(const fs_grid *g, const float *div, float *pa,
 int fs_k_project_n_cfl(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, float *cfl_dev,
                        int *result_in_b, void *stream)
 {
-    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, cfl_dev, result_in_b, stream);
+    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, cfl_dev, result_in_b, stream, 0);
 }
 
 int fs_k_project_n(const fs_grid *g, float *u, float *v, float *div, float *pa, float *pb, int n, int *result_in_b,
                    void *stream)
 {
-    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, nullptr, result_in_b, stream);
+    return fs::project_n_cfl(fs::default_tuning(), g, u, v, div, pa, pb, n, nullptr, result_in_b, stream, 0);
 }
 
 int fs_k_pressureSolve(const fs_grid *g, const float *div, const float *p, float *pOut, void *stream)

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(GK g, int yb, int ye,
         __syncthreads();
         if (tid == 0) {
             m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-            if (m > 0.0f) atomicMax(cfl, __float_as_uint(m));
+            if (m > 0.0f) atomic_max_if_larger(cfl, __float_as_uint(m));
         }
         return;
     }
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void k_max_abs(GK g, int yb, int ye, const flo
         for (int x = nq * 4 + threadIdx.x; x < g.W; x += 256) m = fmaxf(m, fabsf(row[x]));
     }
     for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomic_max_if_larger(out, __float_as_uint(m));
 }
 
 static inline dim3 quad_grid(const fs_grid *g, int nplanes)

@@ -67,15 +67,34 @@ fs_grid grid_of(const fs_ctx *c, int depth)
 // planes in the Infinity Cache), at least two launches, and enough tiles that each band still fills the chip once.
 bool bands_wanted(const fs_ctx *c, int N)
 {
-    if (c->world > 1 || !c->split_rows || !c->stream2 || c->dry) return false;
+    if (!c->split_rows || !c->stream2 || c->dry) return false;
     // (launched eagerly the fork / join events cost more than the bands gain: frames that are never replayed keep one chain;
     // FS_STAGE_PROJECT, a test and measurement hook, runs the bands either way)
     if (jacobi_launch_count(c->tuning, 0, N) < 2) return false;
-    const bool cache_resident = 3.0 * (double)c->pitch * (double)c->H * sizeof(float) < 192.0 * 1024 * 1024;
+    // a slab: its own rows (the nominal height, so that every rank decides alike) plus the ghost rows the loop reads
+    const int rows = c->world > 1 ? c->H / c->world : c->H;
+    const double loop_rows = c->world > 1 ? (double)(rows + 2 * (N + 1)) : (double)rows;
+    const bool cache_resident = 3.0 * (double)c->pitch * loop_rows * sizeof(float) < 192.0 * 1024 * 1024;
     if (!(c->fuse >= 3 || (c->fuse == 1 && cache_resident))) return false;
+    if (c->world > 1 && c->G < N + 1) return false;   // the fused projection needs N + 1 ghost rows of velocity
     const int T = std::min(c->tuning.depth[0], N), oh = std::max(8, 64 - 2 * T);   // (the default 256 x 64 tile)
-    const long tiles = (long)((c->W + 231) / 232) * (long)((c->H + oh - 1) / oh);
-    return tiles >= 768 && c->H >= 8 * (N + 2);
+    const long tiles = (long)((c->W + 231) / 232) * (long)((rows + oh - 1) / oh);
+    return tiles >= 768 && rows >= 8 * (N + 2);
+}
+
+// band B of a two-band projection iterates in two private planes (allocated outside any capture)
+void ensure_band_planes(fs_ctx *c, int N)
+{
+    if (c->p_band[0] || !bands_wanted(c, N)) return;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipMalloc((void **)&c->p_band[i], c->plane * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(c->p_band[0]);
+            c->p_band[0] = c->p_band[1] = nullptr;   // the loop then stays one chain
+            break;
+        }
+    }
 }
 
 namespace {
@@ -222,14 +241,14 @@ struct Planner {
                     c->p_band_final = jacobi_launch_count(tn, 0, n) & 1;
                     compute("project_n (2 bands)", g, n, [=]() {                      // Solver:522-547
                         int ib = 0;
-                        return project_n_bands(tn, &g, split, u, v, dw, src, dst, qa, qb, n, &ib, st, st2, ef, ej, ea, eb);
+                        return project_n_bands(tn, &g, split, u, v, dw, src, dst, qa, qb, n, &ib, st, st2, ef, ej, ea, eb, nullptr, 0);
                     });
                 }
                 else if (with_gradient) {
                     float *dw = c->f[F_DIV].p();
                     compute("project_n", g, n, [=]() {                                // Solver:522-547
                         int ib = 0;
-                        return project_n_cfl(tn, &g, u, v, dw, src, dst, n, nullptr, &ib, st);
+                        return project_n_cfl(tn, &g, u, v, dw, src, dst, n, nullptr, &ib, st, 0);
                     });
                 }
                 else
@@ -261,7 +280,7 @@ struct Planner {
                     return rc1 ? rc1 : rc2;
                 });
             }
-            if (jacobi_launch_count(c->tuning, pressure ? 0 : 1, n) & 1) F.cur ^= 1;
+            if (jacobi_launch_count(c->tuning, pressure ? 0 : 1, n) & 1) F.flip();
             if (multi) F.valid = out_depth;
             remaining -= n;
         }
@@ -302,7 +321,7 @@ struct Planner {
     void advect(int fi, bool fade, int depth = 0)
     {
         advect_rows(fi, fade, c->r0 - depth, c->r1 + depth);
-        c->f[fi].cur ^= 1;                                                            // Solver:558, :584
+        c->f[fi].flip();                                                            // Solver:558, :584
         if (multi) c->f[fi].valid = depth;
     }
 
@@ -345,7 +364,7 @@ struct Planner {
                 float *uo = V.t(), *vo = off(uo, plane);
                 const float strength = p.vorticityStrength;
                 compute("vorticity_apply", g, 0, [=]() { return fs_k_vorticity_apply(&g, u, v, uo, vo, strength, dt, st); });   // :486-502
-                V.cur ^= 1;
+                V.flip();
             } else {
                 {
                     const fs_grid g = grid_of(c, dw);
@@ -388,15 +407,27 @@ struct Planner {
         if (project_fused && multi) {
             const fs_grid g = grid_of(c, 0);
             Field &P = c->f[F_P];
-            float *u = V.p(), *v = off(u, plane), *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = c->cfl_dev;
+            float *u = V.p(), *v = off(u, plane), *dw = c->f[F_DIV].p(), *src = P.p(), *dst = P.t(), *cfl = off(c->cfl_dev, c->cfl_slot);
             const JacobiTuning tn = c->tuning;
+            // as two row bands out of step, like the single-GPU frame (project_n_bands), when the launches are replayed
+            const int split = ((c->r0 + c->r1) / 2 + 3) & ~3;
+            if (c->use_graph && bands_wanted(c, N) && c->p_band[0] && split > g.yb && split < g.ye) {
+                float *qa = c->p_band[0], *qb = c->p_band[1];
+                hipStream_t st2 = c->stream2;
+                hipEvent_t ef = c->ev_fork, ej = c->ev_join, ea = c->ev_band[0], eb = c->ev_band[1];
+                c->p_band_active = true;
+                c->p_band_row = split;
+                c->p_band_final = jacobi_launch_count(tn, 0, N) & 1;
+                compute("project_n_cfl", g, N, [=]() {                                // :522-547 + the CFL bound
+                    int ib = 0;
+                    return project_n_bands(tn, &g, split, u, v, dw, src, dst, qa, qb, N, &ib, st, st2, ef, ej, ea, eb, cfl, 1);
+                });
+            } else
             compute("project_n_cfl", g, N, [=]() {                                    // :522-547 + the CFL bound
-                hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
-                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
                 int ib = 0;
-                return project_n_cfl(tn, &g, u, v, dw, src, dst, N, cfl, &ib, st);
+                return project_n_cfl(tn, &g, u, v, dw, src, dst, N, cfl, &ib, st, 1);
             });
-            if (jacobi_launch_count(c->tuning, 0, N) & 1) P.cur ^= 1;
+            if (jacobi_launch_count(c->tuning, 0, N) & 1) P.flip();
             P.valid = 0;
             c->f[F_DIV].valid = 0;
             c->p_zero = false;
@@ -418,7 +449,7 @@ struct Planner {
                 compute("subtractGradient", g, 0, [=]() { return fs_k_subtractGradient(&g, pp, u, v, st); }); // :544-547
             } else {
                 // ... and, in the same pass, the CFL bound of the backtrace: max |v_y| over the owned rows
-                float *cfl = c->cfl_dev;
+                float *cfl = off(c->cfl_dev, c->cfl_slot);
                 compute("subtractGradient_cfl", g, 0, [=]() {
                     hipError_t e = hipMemsetAsync(cfl, 0, sizeof(float), st);
                     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(cfl)");
@@ -460,19 +491,19 @@ struct Planner {
                 advect_both_rows(i0, i1);
             } else {
                 advect_rows(F_VEL, false, i0, i1);
-                c->f[F_VEL].cur ^= 1;
+                c->f[F_VEL].flip();
                 advect_rows(F_DYE, fade_fused, i0, i1);
-                c->f[F_VEL].cur ^= 1;
+                c->f[F_VEL].flip();
             }
             join(SLOT_VEL);
             advect_rows(F_VEL, false, c->r0 - adv, i0);
             advect_rows(F_VEL, false, i1, c->r1 + adv);
-            c->f[F_VEL].cur ^= 1;                                                     // :558
+            c->f[F_VEL].flip();                                                     // :558
             c->f[F_VEL].valid = adv;
             join(SLOT_DYE);
             advect_rows(F_DYE, fade_fused, c->r0, i0);
             advect_rows(F_DYE, fade_fused, i1, c->r1);
-            c->f[F_DYE].cur ^= 1;                                                     // :584
+            c->f[F_DYE].flip();                                                     // :584
         } else {
             if (multi) {
                 ensure({{F_VEL, h + adv}, {F_DYE, h + ddn}});                         // one batched round
@@ -480,8 +511,8 @@ struct Planner {
             }
             if (!multi && !ddn && both_fused) {
                 advect_both_rows(c->r0, c->r1);                                       // :550-558 + :577-591 in one pass
-                c->f[F_VEL].cur ^= 1;
-                c->f[F_DYE].cur ^= 1;
+                c->f[F_VEL].flip();
+                c->f[F_DYE].flip();
             } else {
                 advect(F_VEL, false, adv);                                            // :550-558
                 if (ddn && dye_diffusion_hoisted()) {                                 // planned by plan_a: wait for it here
@@ -659,6 +690,16 @@ void plan_update_b(fs_ctx *c, int h) { Planner(c).plan_b(h); }
 
 namespace {
 
+// "everything enqueued on the main stream so far": what a transfer or the CFL reduction on the exchange stream waits for.
+// Two of those back to back (the reduction and the velocity exchange after the projection) share one marker.
+int mark_main(fs_ctx *c)
+{
+    if (c->ev_main_fresh) return FS_OK;
+    FS_HIP(hipEventRecord(c->ev_main, c->stream));
+    c->ev_main_fresh = true;
+    return FS_OK;
+}
+
 int join_slot(fs_ctx *c, int slot)
 {
     if (!c->pending[slot]) return FS_OK;
@@ -693,7 +734,7 @@ int exchange_phase(fs_ctx *c, const Step &st, int phase)
         c->stat_exchanges += 1;
         for (const Seg &s : segs)
             if (s.send) c->stat_rows += s.y1 - s.y0;
-        if (cm->kind != 0) FS_HIP(hipEventRecord(c->ev_main, c->stream));
+        if (cm->kind != 0) return mark_main(c);
         return FS_OK;
     }
     if (phase == 1) {
@@ -707,6 +748,24 @@ int exchange_phase(fs_ctx *c, const Step &st, int phase)
                 if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(r, s.send ? "ncclSend" : "ncclRecv"); }
             }
             FS_NCCL(g_rccl.GroupEnd());
+            FS_HIP(hipEventRecord(c->ev_slot[st.slot], c->xstream));
+            return FS_OK;
+        }
+        if (cm->kind == 3) {
+            // loopback: rows of the same count out of my own slab (timing only, see fs_comm)
+            FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
+            const int own = c->r1 - c->r0;
+            for (const Seg &s : segs) {
+                if (s.send) continue;
+                for (int a = s.y0; a < s.y1; a += own) {
+                    const int cnt = std::min(own, s.y1 - a);
+                    Seg dst = s, src = s;
+                    dst.y0 = a;
+                    src.y0 = a < c->r0 ? c->r0 : c->r1 - cnt;   // rows above me <- my first rows, rows below me <- my last rows
+                    FS_HIP(hipMemcpyAsync(seg_ptr(c, dst), seg_ptr(c, src), (size_t)cnt * c->pitch * sizeof(float), hipMemcpyDeviceToDevice,
+                                          c->xstream));
+                }
+            }
             FS_HIP(hipEventRecord(c->ev_slot[st.slot], c->xstream));
             return FS_OK;
         }
@@ -753,21 +812,30 @@ int exchange_phase(fs_ctx *c, const Step &st, int phase)
     return st.async ? FS_OK : join_slot(c, st.slot);
 }
 
-// max over ranks of the per-slab CFL bound; the value lands in pinned host memory behind ev_cfl
+// max over ranks of the per-slab CFL bound of the frame being enqueued (slot c->cfl_slot); the value lands in pinned host
+// memory behind ev_cfl[slot]
 int cfl_phase(fs_ctx *c, int phase)
 {
     fs_comm *cm = c->comm;
     if (!cm) { set_error("CFL reduction planned on a context without a communicator"); return FS_ERR_STATE; }
     if (phase == 0) {
-        if (cm->kind != 0) FS_HIP(hipEventRecord(c->ev_main, c->stream));
+        if (cm->kind != 0) return mark_main(c);
         return FS_OK;
     }
     if (phase != 1) return FS_OK;
+    const int slot = c->cfl_slot;
+    float *dev = c->cfl_dev + slot, *host = c->cfl_host + (size_t)slot * c->world;
     if (cm->kind == 1) {
         FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
-        FS_NCCL(g_rccl.AllReduce(c->cfl_dev, c->cfl_dev, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, c->xstream));
-        FS_HIP(hipMemcpyAsync(c->cfl_host, c->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
-        FS_HIP(hipEventRecord(c->ev_cfl, c->xstream));
+        FS_NCCL(g_rccl.AllReduce(dev, dev, 1, ncclFloat, ncclMax, (ncclComm_t)cm->nccl, c->xstream));
+        FS_HIP(hipMemcpyAsync(host, dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
+        FS_HIP(hipEventRecord(c->ev_cfl[slot], c->xstream));
+        return FS_OK;
+    }
+    if (cm->kind == 3) {   // loopback: my own bound
+        FS_HIP(hipStreamWaitEvent(c->xstream, c->ev_main, 0));
+        FS_HIP(hipMemcpyAsync(host, dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
+        FS_HIP(hipEventRecord(c->ev_cfl[slot], c->xstream));
         return FS_OK;
     }
     if (cm->kind == 0) {
@@ -778,27 +846,28 @@ int cfl_phase(fs_ctx *c, int phase)
     for (fs_ctx *x : cm->members) {
         if (cm->kind == 2) {
             FS_HIP(hipStreamWaitEvent(c->xstream, x->ev_main, 0));
-            FS_HIP(hipMemcpyAsync(&c->cfl_host[x->rank], x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
+            FS_HIP(hipMemcpyAsync(&host[x->rank], x->cfl_dev + slot, sizeof(float), hipMemcpyDeviceToHost, c->xstream));
         } else {
-            FS_HIP(hipMemcpy(&c->cfl_host[x->rank], x->cfl_dev, sizeof(float), hipMemcpyDeviceToHost));
+            FS_HIP(hipMemcpy(&host[x->rank], x->cfl_dev + slot, sizeof(float), hipMemcpyDeviceToHost));
         }
     }
-    if (cm->kind == 2) FS_HIP(hipEventRecord(c->ev_cfl, c->xstream));
+    if (cm->kind == 2) FS_HIP(hipEventRecord(c->ev_cfl[slot], c->xstream));
     return FS_OK;
 }
 
-int wait_cfl(fs_ctx *c)
+int wait_cfl(fs_ctx *c, int slot)
 {
     fs_comm *cm = c->comm;
     if (cm->kind != 0) {
         const auto t0 = std::chrono::steady_clock::now();
-        FS_HIP(hipEventSynchronize(c->ev_cfl));
+        FS_HIP(hipEventSynchronize(c->ev_cfl[slot]));
         c->host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
-    const int k = cm->kind == 1 ? 1 : cm->world;
+    const int k = cm->solo() ? 1 : cm->world;
+    const float *host = c->cfl_host + (size_t)slot * c->world;
     float m = 0.0f;
     for (int i = 0; i < k; ++i)
-        if (!(c->cfl_host[i] <= m)) m = c->cfl_host[i];   // NaN propagates
+        if (!(host[i] <= m)) m = host[i];   // NaN propagates
     c->cfl_max = m;
     return FS_OK;
 }
@@ -813,10 +882,12 @@ int tracer_phase(fs_ctx *c, int phase)
 {
     fs_comm *cm = c->comm;
     if (!cm) { set_error("tracer step planned on a context without a communicator"); return FS_ERR_STATE; }
+    if (cm->kind == 3) { set_error("a loopback slab (measurement aid) has no tracer step"); return FS_ERR_STATE; }
     if (c->max_particles <= 0 || !c->tr_counts_dev) { set_error("tracers on a slab need fs_particles_reserve first"); return FS_ERR_STATE; }
     const int W = c->world, me = c->rank;
     const fs_grid g = grid_of(c, 0);
     const long n = c->n_particles;
+    c->ev_main_fresh = false;
     if (phase == 0) {
         FS_HIP(hipMemsetAsync(c->tr_counts_dev, 0, (size_t)W * sizeof(int), c->stream));
         int rc = fs_k_tracer_count(&g, &c->pparams, W, me, n, c->part[1], c->part[4], c->tr_counts_dev, c->stream);
@@ -926,6 +997,95 @@ int halo_from_cfl(fs_ctx *c, int *h)
     return FS_OK;
 }
 
+struct HostTimer {
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit HostTimer(double &a) : acc(a) {}
+    ~HostTimer() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// ---- segments: the exchange-free runs of kernel launches of a slab's plan, replayed as hipGraphs ----------------
+// What decides the launches of a segment: the ping-pong roles the plan started from and which plan it is (plan_salt),
+// where the segment sits in the plan, every step's stage / row range / sweep count, and the scalars baked into the
+// kernel arguments.  Options and tuning are not hashed: changing one drops the graphs (fs_set_option).
+unsigned long long segment_key(const fs_ctx *c, size_t i, size_t j)
+{
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t k = 0; k < n; ++k) { h ^= b[k]; h *= 1099511628211ull; }
+    };
+    mix(&c->plan_salt, sizeof(c->plan_salt));
+    mix(&i, sizeof(i));
+    // (field by field: the struct's padding bytes are not ours to hash)
+    const fs_params &p = c->params;
+    mix(&p.viscosity, sizeof(float)); mix(&p.diffusion, sizeof(float)); mix(&p.deltaTime, sizeof(float));
+    mix(&p.vorticityStrength, sizeof(float)); mix(&p.fadeSpeed, sizeof(float)); mix(&p.brightness, sizeof(float));
+    mix(&p.solverIterations, sizeof(int)); mix(&p.displayMode, sizeof(int));
+    for (size_t k = i; k < j; ++k) {
+        const Step &s = c->steps[k];
+        mix(s.what, strlen(s.what) + 1);
+        const int v[3] = {s.yb, s.ye, s.n};
+        mix(v, sizeof(v));
+    }
+    return h;
+}
+
+int run_steps_eager(fs_ctx *c, size_t i, size_t j)
+{
+    for (size_t k = i; k < j; ++k) {
+        const int rc = c->steps[k].run();
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
+// steps [i, j) of c's plan are all kernel launches on the context's own streams.  Runs of one or two steps (the split
+// advection: interior, rims) are launched as they are: a replay would save nothing, and their row ranges follow the
+// advection halo, which changes from frame to frame.
+int run_segment(fs_ctx *c, size_t i, size_t j)
+{
+    c->ev_main_fresh = false;
+    const bool graph = c->world > 1 && !c->dry && c->use_graph && c->stable_frames >= c->seg_min_stable && j - i >= 3;
+    if (!graph) {
+        HostTimer t(c->host_part_us[3]);
+        if (c->world > 1) c->stat_seg_eager += 1;
+        return run_steps_eager(c, i, j);
+    }
+    const unsigned long long key = segment_key(c, i, j);
+    auto it = c->seg_graphs.find(key);
+    if (it != c->seg_graphs.end()) {
+        HostTimer t(c->host_part_us[1]);
+        FS_HIP(hipGraphLaunch(it->second, c->stream));
+        c->stat_seg_replays += 1;
+        return FS_OK;
+    }
+    HostTimer t(c->host_part_us[2]);
+    if (c->seg_graphs.size() >= 96) drop_segment_graphs(c);   // (halo depths that keep changing: start over rather than grow)
+    hipGraph_t g = nullptr;
+    FS_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    const int rc = run_steps_eager(c, i, j);
+    const hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        if (rc) return rc;
+        return hip_fail(e, "hipStreamEndCapture(segment)");
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) {   // nothing has run yet: this runtime cannot replay the segment, launch it eagerly from now on
+        (void)hipGetLastError();
+        c->use_graph = 0;
+        c->stat_seg_eager += 1;
+        return run_steps_eager(c, i, j);
+    }
+    c->seg_graphs[key] = exec;
+    c->stat_seg_captures += 1;
+    FS_HIP(hipGraphLaunch(exec, c->stream));
+    return FS_OK;
+}
+
 // the planned steps of all n slabs, in lock step (n = 1: a plain walk)
 int exec_all(fs_ctx **cs, int n)
 {
@@ -935,22 +1095,38 @@ int exec_all(fs_ctx **cs, int n)
             set_error("rank %d planned %zu steps, rank 0 %zu", r, cs[r]->steps.size(), count);
             return ctx_fail(cs[r], FS_ERR_STATE);
         }
-    for (size_t i = 0; i < count; ++i) {
+    for (size_t i = 0; i < count;) {
         const int kind = cs[0]->steps[i].kind;
+        if (kind == STEP_COMPUTE) {
+            // a run of kernel launches: nothing in it involves another rank (every rank plans the same kinds)
+            size_t j = i;
+            while (j < count && cs[0]->steps[j].kind == STEP_COMPUTE) ++j;
+            for (int r = 0; r < n; ++r) {
+                fs_ctx *c = cs[r];
+                if (n > 1) CTX(c);
+                for (size_t k = i; k < j; ++k)
+                    if (c->steps[k].kind != STEP_COMPUTE) { set_error("rank %d: step %zu is not a launch", r, k); return ctx_fail(c, FS_ERR_STATE); }
+                fs_comm *cm = c->comm;
+                const bool serial = n > 1 && cm && cm->serialize && c->ev_serial;
+                if (serial && cm->last_serial) TRYHIP(c, hipStreamWaitEvent(c->stream, cm->last_serial, 0));
+                TRY(c, run_segment(c, i, j));
+                if (serial) { TRYHIP(c, hipEventRecord(c->ev_serial, c->stream)); cm->last_serial = c->ev_serial; }
+            }
+            i = j;
+            continue;
+        }
         const int phases = kind == STEP_EXCHANGE || kind == STEP_CFL_REDUCE || kind == STEP_TRACERS ? 3 : 1;
         for (int phase = 0; phase < phases; ++phase)
             for (int r = 0; r < n; ++r) {
                 fs_ctx *c = cs[r];
                 if (n > 1) CTX(c);
+                HostTimer t(c->host_part_us[kind == STEP_EXCHANGE ? 4 : kind == STEP_CFL_REDUCE ? 5 : kind == STEP_JOIN ? 6 : 7]);
                 TRY(c, exec_phase(c, c->steps[i], phase));
             }
+        ++i;
     }
     return FS_OK;
 }
-
-struct Saved {
-    Field f[F_COUNT];
-};
 
 }  // namespace
 
@@ -965,65 +1141,220 @@ int run_frames(fs_ctx **cs, int n)
     cs[0]->host_frames += 1;
     return rc;
 }
+static unsigned long long roles_of(const fs_ctx *c)
+{
+    return (unsigned long long)c->f[F_VEL].cur | ((unsigned long long)c->f[F_VEL].oth << 2) | ((unsigned long long)c->f[F_DYE].cur << 4) |
+           ((unsigned long long)c->f[F_P].cur << 5) | ((unsigned long long)c->cfl_slot << 6);
+}
+// plan B of one frame on every slab: advection .. render.  hold_tracers: without the tracer step, which is collective
+// and host-synchronous and must run once, after the advection is known to be right (tracer_part)
+static int advect_part(fs_ctx **cs, int n, int h, bool hold_tracers)
+{
+    for (int r = 0; r < n; ++r) {
+        fs_ctx *c = cs[r];
+        HostTimer t(c->host_part_us[0]);
+        c->steps.clear();
+        c->plan_salt = 0x200ull | roles_of(c);
+        plan_update_b(c, h);
+        if (hold_tracers && !c->steps.empty() && c->steps.back().kind == STEP_TRACERS) c->steps.pop_back();
+    }
+    return exec_all(cs, n);
+}
+static int tracer_part(fs_ctx **cs, int n)
+{
+    for (int r = 0; r < n; ++r) {
+        Step s;
+        s.kind = STEP_TRACERS;
+        s.what = "tracers";
+        cs[r]->steps.clear();
+        cs[r]->steps.push_back(std::move(s));
+    }
+    return exec_all(cs, n);
+}
+static void push_halo(fs_ctx *c, int h_true)
+{
+    int *hist = c->halo_hist;
+    hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = h_true;
+}
+
+// The check a speculating frame owes: was the guessed advection halo deep enough?  (All ranks hold the same
+// all-reduced bound and the same guess, so all take the same decision.)  Returns the frame's true halo; *miss: the
+// guess was too small, some backtraces of that frame's advection read stale ghost rows.
+static int check_pending(fs_ctx **cs, int n, int *h_true, bool *miss)
+{
+    for (int r = 0; r < n; ++r) cs[r]->chk_pending = false;
+    for (int r = 0; r < n; ++r) {
+        if (n > 1) CTX(cs[r]);
+        TRY(cs[r], wait_cfl(cs[r], cs[r]->chk_slot));
+        TRY(cs[r], halo_from_cfl(cs[r], h_true));
+    }
+    *miss = *h_true > cs[0]->chk_h;
+    return FS_OK;
+}
+// Advection wrote only the ping-pong partners and its inputs are intact (the velocity it read is in the spare role or
+// still the partner: nothing has been allowed to overwrite it): plan it again with the true depth from the roles it
+// started from, then repeat the splats that have been applied to its output since.
+static int repair_advection(fs_ctx **cs, int n, int h_true)
+{
+    for (int r = 0; r < n; ++r) {
+        fs_ctx *c = cs[r];
+        if (n > 1) CTX(c);
+        for (int slot = 0; slot < SLOT_COUNT; ++slot) TRY(c, join_slot(c, slot));   // transfers a discarded chain had in flight
+        std::copy(c->chk_saved, c->chk_saved + F_COUNT, c->f);
+        c->stat_redo += 1;
+    }
+    int rc = advect_part(cs, n, h_true, true);   // (a tracer step, if any, follows the check: run_frames_impl)
+    if (rc) return rc;
+    for (int r = 0; r < n; ++r) {
+        fs_ctx *c = cs[r];
+        if (n > 1) CTX(c);
+        const fs_grid g = grid_of(c, c->G);
+        float *u = c->f[F_VEL].p(), *v = u + c->plane, *d = c->f[F_DYE].p();
+        c->ev_main_fresh = false;
+        for (const fs_ctx::Splat &sp : c->splat_log)
+            TRY(c, fs_k_addForces(&g, u, v, d, d + c->plane, d + 2 * c->plane, sp.px, sp.py, sp.fx, sp.fy, sp.r, sp.g, sp.b,
+                                  sp.radius, sp.dt, c->stream));
+        c->steps.clear();
+    }
+    return FS_OK;
+}
+
+// the check at a call that has not enqueued anything on top of the frame (fs_sync, a read, a frame that cannot run ahead)
+static int settle_all(fs_ctx **cs, int n)
+{
+    if (!cs[0]->chk_pending) return FS_OK;
+    int h_true = 0;
+    bool miss = false;
+    int rc = check_pending(cs, n, &h_true, &miss);
+    if (rc) return rc;
+    if (miss && (rc = repair_advection(cs, n, h_true))) return rc;
+    for (int r = 0; r < n; ++r) {
+        cs[r]->splat_log.clear();
+        push_halo(cs[r], h_true);
+    }
+    return FS_OK;
+}
+
+int settle(fs_ctx *c)
+{
+    if (!c || !c->chk_pending) return FS_OK;
+    fs_comm *cm = c->comm;
+    if (!cm || cm->solo()) return settle_all(&c, 1);
+    for (fs_ctx *m : cm->members)
+        if (!m) { c->chk_pending = false; c->splat_log.clear(); return FS_OK; }   // the group is being torn down
+    std::vector<fs_ctx *> cs(cm->members);
+    const int rc = settle_all(cs.data(), (int)cs.size());
+    (void)hipSetDevice(c->device);
+    return rc;
+}
+
+void drop_segment_graphs(fs_ctx *c)
+{
+    for (auto &kv : c->seg_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->seg_graphs.clear();
+}
+
+static int guess_halo(const fs_ctx *c)
+{
+    // the bound is set by the newest splat's jet and jumps by 2x from frame to frame (profiles/r01_probe_halo_series.log):
+    // the envelope of the last four frames known, + 25 % + 4 rows
+    const int envelope = *std::max_element(c->halo_hist, c->halo_hist + 4);
+    return std::min(c->G, (envelope * 5 + 3) / 4 + 4);
+}
+
+// update() up to the CFL reduction on every slab (plan A); h_dye >= 0: prefetch the dye halo of that depth
+static int chain_part(fs_ctx **cs, int n, int h_dye)
+{
+    for (int r = 0; r < n; ++r) {
+        HostTimer t(cs[r]->host_part_us[0]);
+        cs[r]->steps.clear();
+        cs[r]->plan_salt = 0x100ull | roles_of(cs[r]);
+        plan_update_a(cs[r], h_dye);
+    }
+    return exec_all(cs, n);
+}
+
+// One frame on n slabs.  A slab frame that may speculate runs one frame ahead of its checks:
+//   frame f:      chain (A) | advection with a GUESSED halo (B), roles from before B remembered      -> returns, no wait
+//   frame f + 1:  velocity roles rotated, so that this chain writes into the spare and B(f)'s input survives | chain (A)
+//                 | only now the host looks at frame f's all-reduced bound -- by then long there, while the GPU has B(f)
+//                 and this chain queued, so it never runs dry | guess too small (rare): B(f) again with the true depth
+//                 from the remembered roles, the splats since repeated, the chain again | B(f + 1) ...
+// Any other call on the context (fs_sync, a read ...) runs the owed check first (settle).
 static int run_frames_impl(fs_ctx **cs, int n)
 {
     fs_ctx *c0 = cs[0];
     const bool multi = c0->world > 1;
     const fs_params &p = c0->params;
     const bool ddn = p.diffusion > 0.0f && p.solverIterations > 0;
-    // speculate on the advection halo when the previous frame's is known and the advection can be redone
-    // (the guess: the bound is set by the newest splat's jet and jumps by 2x from frame to frame --
-    // profiles/r01_probe_halo_series.log -- so it is the envelope of the last four frames, + 25 % + 4 rows)
-    const int envelope = *std::max_element(c0->halo_hist, c0->halo_hist + 4);
-    const bool spec = multi && c0->overlap && c0->halo_hist[0] >= 0 && !ddn;
+    const bool tracers = multi && c0->with_particles;
+    const bool may_spec = multi && c0->overlap && !ddn;
+    // check the last frame AFTER this frame's chain is enqueued?  Needs the spare velocity buffer and a frame that
+    // speculates itself (its chain then ends without the host reading anything back)
+    for (int r = 0; r < n; ++r) cs[r]->ev_main_fresh = false;   // (splats, writes, stages ... since the last frame)
+    const bool late = c0->chk_pending && may_spec && c0->defer_check && !tracers && c0->f[F_VEL].buf[2] != nullptr;
+    int rc;
+    if (!late && (rc = settle_all(cs, n))) return rc;
+    if (multi)
+        for (int r = 0; r < n; ++r) {
+            if (n > 1) CTX(cs[r]);
+            ensure_band_planes(cs[r], p.solverIterations);
+            cs[r]->cfl_slot ^= 1;
+        }
+    const bool spec = may_spec && c0->halo_hist[0] >= 0;
     int h = 0;
-    if (spec) h = std::min(c0->G, (envelope * 5 + 3) / 4 + 4);
-    for (int r = 0; r < n; ++r) {
-        cs[r]->steps.clear();
-        plan_update_a(cs[r], spec ? h : -1);
+    if (late) {
+        for (int r = 0; r < n; ++r) cs[r]->f[F_VEL].rotate();
+        // (the dye prefetch is sized without the last frame's bound; B below is sized with it and tops the dye halo up if need be)
+        if ((rc = chain_part(cs, n, guess_halo(c0)))) return rc;
+        int h_last = 0;
+        bool miss = false;
+        if ((rc = check_pending(cs, n, &h_last, &miss))) return rc;
+        if (miss) {
+            // this chain ran on a wrong velocity: put B(f) right, then enqueue the chain again (same CFL slot: nobody
+            // has waited for the discarded reduction)
+            if ((rc = repair_advection(cs, n, h_last))) return rc;
+            for (int r = 0; r < n; ++r) { push_halo(cs[r], h_last); cs[r]->splat_log.clear(); cs[r]->f[F_VEL].rotate(); }
+            if ((rc = chain_part(cs, n, guess_halo(c0)))) return rc;
+        } else {
+            for (int r = 0; r < n; ++r) { push_halo(cs[r], h_last); cs[r]->splat_log.clear(); }
+        }
+        h = guess_halo(c0);
+    } else {
+        if (spec) h = guess_halo(c0);
+        if ((rc = chain_part(cs, n, spec ? h : -1))) return rc;
     }
-    int rc = exec_all(cs, n);
-    if (rc) return rc;
     int h_true = 0;
     if (multi && !spec) {
         for (int r = 0; r < n; ++r) {
-            TRY(cs[r], wait_cfl(cs[r]));
+            TRY(cs[r], wait_cfl(cs[r], cs[r]->cfl_slot));
             TRY(cs[r], halo_from_cfl(cs[r], &h_true));
         }
         h = h_true;
     }
-    std::vector<Saved> saved(spec ? n : 0);
-    for (int r = 0; r < n; ++r) {
-        if (spec) std::copy(cs[r]->f, cs[r]->f + F_COUNT, saved[r].f);
-        cs[r]->steps.clear();
-        plan_update_b(cs[r], h);
-    }
-    if ((rc = exec_all(cs, n))) return rc;
-    if (spec) {
+    if (spec)
         for (int r = 0; r < n; ++r) {
-            TRY(cs[r], wait_cfl(cs[r]));
-            TRY(cs[r], halo_from_cfl(cs[r], &h_true));
+            fs_ctx *c = cs[r];
+            std::copy(c->f, c->f + F_COUNT, c->chk_saved);
+            c->chk_h = h;
+            c->chk_slot = c->cfl_slot;
+            c->splat_log.clear();
         }
-        if (h_true > h) {
-            // The guess was too small: some backtraces read stale ghost rows.  Advection wrote only the
-            // ping-pong partners, so its inputs are intact: plan it again with the true depth.
-            for (int r = 0; r < n; ++r) {
-                fs_ctx *c = cs[r];
-                std::copy(saved[r].f, saved[r].f + F_COUNT, c->f);
-                c->stat_redo += 1;
-                c->steps.clear();
-                plan_update_b(c, h_true);
-            }
-            if ((rc = exec_all(cs, n))) return rc;
+    if ((rc = advect_part(cs, n, h, spec && tracers))) return rc;
+    if (spec) {
+        for (int r = 0; r < n; ++r) cs[r]->chk_pending = true;
+        // the check is put off to the next call unless something host-synchronous follows in this frame anyway
+        if (!c0->defer_check || tracers) {
+            if ((rc = settle_all(cs, n))) return rc;
         }
+    } else if (multi) {
+        for (int r = 0; r < n; ++r) push_halo(cs[r], h_true);
     }
+    if (spec && tracers && (rc = tracer_part(cs, n))) return rc;
     for (int r = 0; r < n; ++r) {
         cs[r]->steps.clear();
         cs[r]->stat_frames += 1;
-        if (multi) {
-            int *hist = cs[r]->halo_hist;
-            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = h_true;
-        }
+        if (multi) { cs[r]->stable_frames += 1; cs[r]->p_band_dirty = cs[r]->p_band_active; }
     }
     return FS_OK;
 }
@@ -1107,6 +1438,14 @@ static int create_local(int world, int kind, fs_comm **out)
 
 int fs_comm_create_local(int world, fs_comm **out) { return create_local(world, 0, out); }
 
+int fs_comm_create_loopback(int world, int rank, fs_comm **out)
+{
+    if (rank < 0 || rank >= world) { set_error("fs_comm_create_loopback: rank %d of %d", rank, world); return FS_ERR_INVALID; }
+    int rc = create_local(world, 3, out);
+    if (!rc) { (*out)->rank = rank; (*out)->members.clear(); }
+    return rc;
+}
+
 int fs_comm_create_local_async(int world, fs_comm **out) { return create_local(world, 2, out); }
 
 int fs_comm_destroy(fs_comm *cm)
@@ -1165,18 +1504,19 @@ int fs_comm_selftest(fs_comm *cm, int count)
 int fs_create_slab(int width, int height, int device, fs_comm *comm, int rank, int ghost_rows, fs_ctx **out)
 {
     if (!comm) { set_error("fs_create_slab: communicator is NULL"); return FS_ERR_INVALID; }
-    if (comm->kind == 1) rank = comm->rank;
+    if (comm->solo()) rank = comm->rank;
     if (rank < 0 || rank >= comm->world) { set_error("fs_create_slab: rank %d of %d", rank, comm->world); return FS_ERR_INVALID; }
     if (comm->kind == 1 && device != comm->device) { set_error("fs_create_slab: the communicator lives on device %d", comm->device); return FS_ERR_INVALID; }
-    if (comm->kind != 1 && comm->members[rank]) { set_error("fs_create_slab: rank %d already exists in this group", rank); return FS_ERR_INVALID; }
+    if (!comm->solo() && comm->members[rank]) { set_error("fs_create_slab: rank %d already exists in this group", rank); return FS_ERR_INVALID; }
     int rc = create_common(width, height, device, comm, comm->world, rank, ghost_rows, 0, false, out);
-    if (!rc && comm->kind != 1) comm->members[rank] = *out;
+    if (!rc && !comm->solo()) comm->members[rank] = *out;
     return rc;
 }
 
 int fs_slab_info(fs_ctx *c, int info[6])
 {
     if (!c || !info) return FS_ERR_INVALID;
+    TRY(c, fs::settle(c));   // (the last advection halo is known once the frame's check has run)
     info[0] = c->r0; info[1] = c->r1; info[2] = c->b0; info[3] = c->b1; info[4] = c->G; info[5] = c->last_halo;
     return FS_OK;
 }
@@ -1186,6 +1526,7 @@ int fs_slab_info(fs_ctx *c, int info[6])
 int fs_slab_waits(fs_ctx *c, double wait_ms[3], long joins[3])
 {
     CTX(c);
+    TRY(c, fs::settle(c));
     if (!wait_ms || !joins) { set_error("fs_slab_waits: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
     if (c->xstream) TRYHIP(c, hipStreamSynchronize(c->xstream));
     TRYHIP(c, hipStreamSynchronize(c->stream));
@@ -1210,9 +1551,24 @@ int fs_slab_host_times(fs_ctx *c, double us[2], long *frames)
     return FS_OK;
 }
 
+int fs_slab_host_breakdown(fs_ctx *c, double us[8])
+{
+    if (!c || !us) return FS_ERR_INVALID;
+    for (int i = 0; i < 8; ++i) { us[i] = c->host_part_us[i]; c->host_part_us[i] = 0.0; }
+    return FS_OK;
+}
+
+int fs_slab_graph_stats(fs_ctx *c, long stats[4])
+{
+    if (!c || !stats) return FS_ERR_INVALID;
+    stats[0] = (long)c->seg_graphs.size(); stats[1] = c->stat_seg_replays; stats[2] = c->stat_seg_captures; stats[3] = c->stat_seg_eager;
+    return FS_OK;
+}
+
 int fs_slab_stats(fs_ctx *c, long stats[5])
 {
     if (!c || !stats) return FS_ERR_INVALID;
+    TRY(c, fs::settle(c));
     stats[0] = c->stat_exchanges; stats[1] = c->stat_rows; stats[2] = c->stat_frames; stats[3] = c->stat_redo;
     stats[4] = c->stat_migrated;
     return FS_OK;
@@ -1222,7 +1578,7 @@ int fs_slab_stats(fs_ctx *c, long stats[5])
 // step i+1 of any, which is the ordering the exchanges of a real multi-process run enforce.
 int fs_group_step(fs_ctx **ctxs, int n)
 {
-    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->comm || ctxs[0]->comm->kind == 1 || ctxs[0]->comm->world != n) {
+    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->comm || ctxs[0]->comm->solo() || ctxs[0]->comm->world != n) {
         set_error("fs_group_step: needs all %d contexts of one local group, in rank order", n);
         return FS_ERR_INVALID;
     }

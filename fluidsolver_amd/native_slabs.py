@@ -116,6 +116,23 @@ class _Slab:
         L.check(self.lib.fs_slab_waits(self.ctx, ms, n), self.ctx)
         return {"vel_ms": ms[0], "dye_ms": ms[1], "blocking_ms": ms[2], "joins": [n[0], n[1], n[2]]}
 
+    def set_option(self, key, value):
+        L.check(self.lib.fs_set_option(self.ctx, int(key), int(value)), self.ctx)
+
+    @property
+    def graph_stats(self):
+        """Segments (exchange-free runs of launches) of this slab's frames: graphs held, replays, recordings, eager runs."""
+        st = (C.c_long * 4)()
+        L.check(self.lib.fs_slab_graph_stats(self.ctx, st))
+        return {"graphs": st[0], "replays": st[1], "captures": st[2], "eager": st[3]}
+
+    def host_breakdown(self):
+        """Since the last call: host us spent planning / replaying / recording segments / launching eagerly / enqueueing
+        exchanges / the CFL reduction / joins / tracer steps."""
+        us = (C.c_double * 8)()
+        L.check(self.lib.fs_slab_host_breakdown(self.ctx, us))
+        return dict(zip(("plan", "replay", "record", "eager", "exchange", "cfl", "join", "tracers"), [float(x) for x in us]))
+
     def host_times(self):
         """Since the last call: us per frame the host spent inside fs_step, and of that blocked on the CFL value."""
         us, n = (C.c_double * 2)(), C.c_long()
@@ -189,6 +206,29 @@ class RcclSlab(_Slab):
 
     def close(self):
         super().close()
+        if getattr(self, "comm", None):
+            self.lib.fs_comm_destroy(self.comm)
+            self.comm = None
+
+
+class LoopbackSlab(_Slab):
+    """Measurement aid: rank `rank` of a `world`-rank run whose peers do not exist (fs_comm_create_loopback).  Stepped like
+    an RcclSlab; does everything that rank would do, with device copies of its own rows in place of the halo rows it would
+    receive.  The fields are meaningless; the TIMING is one rank alone on its GPU with a free wire."""
+
+    def __init__(self, W, H, params, device, rank, world, ghost=None, overlap=True):
+        lib = L.load()
+        comm = C.c_void_p()
+        L.check(lib.fs_comm_create_loopback(int(world), int(rank), C.byref(comm)))
+        self.comm = comm
+        self.rank, self.world = rank, world
+        super().__init__(W, H, params, device, comm, rank, ghost, overlap=overlap)
+
+    update = RcclSlab.update
+    frame = RcclSlab.frame
+
+    def close(self):
+        _Slab.close(self)
         if getattr(self, "comm", None):
             self.lib.fs_comm_destroy(self.comm)
             self.comm = None

@@ -288,6 +288,18 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      of a single-GPU frame runs beside the velocity chain (third stream); 0 = one chain */
        FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
        FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone (default 7: 5 rows per lane x 16 waves) */
+       FS_OPT_SLAB_DEFER = 15,    /* slabs only, same value on every rank: 1 (default) = a frame that speculates on its advection halo
+                                     (FS_OPT_SLAB_OVERLAP) returns without waiting for the all-reduced CFL bound; the check -- and, when
+                                     the guess was too small, the repair: advection planned again with the true depth, the splats
+                                     applied since repeated -- runs at the start of the next call on the context that is not
+                                     fs_add_force (fs_step, fs_sync, a read, fs_slab_info ...), where FS_ERR_HALO is then reported.
+                                     0 = fs_step waits for the bound itself (one device round trip per frame) */
+       FS_OPT_SLAB_SERIALIZE = 17, /* local groups only, a measurement aid (set it on EVERY slab of the group): 1 = the K slabs, which share
+                                     one GPU there, run their launches one slab after the other instead of side by side, so that the
+                                     group's frame takes K x what one slab's frame takes on a GPU of its own (scripts/time_slabs.py) */
+       FS_OPT_SEGMENT_GRAPH_AFTER = 16, /* slabs only: frames the parameters must have stayed put before the exchange-free runs of
+                                     launches of a slab's frame are recorded as hipGraphs and replayed (default 2; FS_OPT_USE_GRAPH = 0
+                                     keeps every launch eager) */
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
                                      depth); 0 = exchange, wait, compute */
@@ -403,6 +415,11 @@ int fs_comm_create_local(int world, fs_comm **out);
 /* The same, but the copies are asynchronous on each slab's exchange stream and ordered only by the
  * events the RCCL path uses: the K slabs run concurrently on the GPU, as K ranks would. */
 int fs_comm_create_local_async(int world, fs_comm **out);
+/* Measurement aid: rank `rank` of a `world`-rank run whose peers do not exist.  A slab created on it is stepped with
+ * fs_step like a rank of an RCCL run and does everything that rank would -- plan, launches, transfers of the same sizes,
+ * CFL reduction, host work -- except that the halo rows it "receives" are copies of its own rows and the CFL bound is
+ * its own: the fields mean nothing, the TIMING is that of one rank alone on its GPU with a free wire (scripts/time_slabs.py). */
+int fs_comm_create_loopback(int world, int rank, fs_comm **out);
 int fs_comm_destroy(fs_comm *comm);   /* after the contexts that use it */
 /* Round trip through an RCCL communicator (collective: every rank calls it): `count` floats to the
  * next rank / from the previous one in one send/recv group, and a 1-float all-reduce(max). */
@@ -426,6 +443,12 @@ int fs_slab_waits(fs_ctx *ctx, double wait_ms[3], long joins[3]);
  * us[1] = the part of it blocked on the CFL value that sizes the advection halo (a device round trip + all-reduce per frame);
  * us[0] - us[1] is what the host spends enqueueing.  frames = calls counted.  (A local group counts on its first slab.) */
 int fs_slab_host_times(fs_ctx *ctx, double us[2], long *frames);
+/* Segments of this slab's frames (exchange-free runs of launches): graphs held, replays, recordings, runs launched eagerly. */
+int fs_slab_graph_stats(fs_ctx *ctx, long stats[4]);
+/* Where the host time of this slab's frames went since the last call, us: [0] planning, [1] segment replays (hipGraphLaunch),
+ * [2] segment recordings, [3] launches made eagerly, [4] exchanges, [5] CFL reduction, [6] joins, [7] tracer steps.  (The wait
+ * for the CFL value is fs_slab_host_times' us[1].) */
+int fs_slab_host_breakdown(fs_ctx *ctx, double us[8]);
 int fs_group_step(fs_ctx **ctxs, int n);      /* update() on all n slabs of a local group, in lock step */
 /* Host only, no GPU: the frame plans (stages with their row ranges, exchanges with their depths) of
  * `frames` consecutive update() calls of one rank, as text; halos[f] = advection halo of frame f;

@@ -144,10 +144,13 @@ def test_config5_slabs_equal_single_gpu_context():
         s.close()
 
 
+@pytest.mark.parametrize("ask", [True, False])
 @pytest.mark.parametrize("mode", sorted(MODES))
-def test_local_group_equals_single_gpu_context_at_size(mode):
+def test_local_group_equals_single_gpu_context_at_size(mode, ask):
     """4 slabs of a 1536 x 1024 grid, N = 40, full-strength scripted splats (advection halo of tens of
-    rows, changing from frame to frame) against fs_step on the whole grid (no oracle: too slow)."""
+    rows, changing from frame to frame) against fs_step on the whole grid (no oracle: too slow).  ask = the halo is
+    read back after every frame, which runs the frame's halo check at once; without it the frames run one ahead of their
+    checks (the velocity roles rotate through the spare buffer)."""
     from fluidsolver_amd import FluidSolver, lib as L
     from fluidsolver_amd.native_slabs import LocalGroup
     from fluidsolver_amd.script import splat
@@ -166,10 +169,13 @@ def test_local_group_equals_single_gpu_context_at_size(mode):
                 s.applyForce(pos, force, col)
             g.update()
             s.update()
-            halos.append(g.slabs[0].last_halo)
+            halos.append(g.slabs[0].last_halo if ask or f == 11 else 9)
         g.sync()
         s.sync()
         assert max(halos) > 8, halos
+        # from the third frame on the exchange-free run of launches of a frame (vorticity .. projection) is a replayed hipGraph
+        gs = [sl.graph_stats for sl in g.slabs]
+        assert all(x["replays"] >= (6 if ask else 3) and 1 <= x["captures"] <= (4 if ask else 7) for x in gs), gs
         assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
         assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
         assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
@@ -235,6 +241,80 @@ def test_wrong_halo_guess_is_replanned():
         assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
         assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
         assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
+    finally:
+        g.close()
+        s.close()
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_deferred_halo_check_repairs_frame_and_splats(defer):
+    """FS_OPT_SLAB_DEFER: fs_group_step returns without waiting for the CFL bound; the check runs at the next call.  Several
+    splats land between a frame whose guess was too small and the call that finds out: the repair must repeat them.  Same
+    bits as one GPU with the check deferred and not."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params = 512, 768, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 10)
+    g = LocalGroup(W, H, params, 3, device=0, asynchronous=True, overlap=True)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        for sl in g.slabs:
+            sl.set_option(L.OPT_SLAB_DEFER, defer)
+        for f, strength in enumerate([5.0, 5.0, 300.0, 5.0, 5.0, 900.0, 1.0, 1.0]):
+            for k in range(3):   # three splats per frame, two of them across slab boundaries
+                pos = (150.0 + 40 * f + 60 * k, 250.0 * (k + 0.02) + 3 * f)
+                force, col = (0.3 * strength, strength * (1 if k != 1 else -1)), (50.0, 20.0 + k, 5.0)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+        g.sync()
+        s.sync()
+        redo = [sl.stats["redo"] for sl in g.slabs]
+        assert redo[0] >= 2 and len(set(redo)) == 1, redo
+        assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY))
+        assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY))
+        assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
+    finally:
+        g.close()
+        s.close()
+
+
+@pytest.mark.parametrize("mode", ["async-overlap", "blocking-plain"])
+def test_projection_as_two_bands_inside_a_slab(mode):
+    """Two slabs of 3072 x 2048: large enough that each slab runs its fused projection as two row bands out of step
+    (replayed segments only), pressure of the lower band in the band's private plane until read.  Against fs_step on the
+    whole 3072 x 4096 grid, N = 40, 7 frames: velocity, dye and pressure bit-identical."""
+    from fluidsolver_amd import FluidSolver, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params = 3072, 4096, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
+    asynchronous, overlap = MODES[mode]
+    g = LocalGroup(W, H, params, 2, device=0, asynchronous=asynchronous, overlap=overlap)
+    s = FluidSolver(W, H)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    try:
+        for f in range(12):
+            for ptr in range(2):
+                pos, force, col = splat(W, H, 5 * f + 1, ptr, 2)
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            g.update()
+            s.update()
+            if f == 9:   # a read in mid-run brings the lower band's rows home; the next frame must not mind
+                assert np.array_equal(g.field("p"), s.read_field(L.FIELD_PRESSURE))
+        g.sync()
+        s.sync()
+        # (six recordings: velocity roles of period 3 -- two buffers + the spare -- times dye / pressure / CFL slot of period 2)
+        gs = [sl.graph_stats for sl in g.slabs]
+        # (and the read in mid-run, which runs the owed check early, shifts the phase of the roles: a few more)
+        assert all(x["replays"] >= 2 and x["captures"] <= 12 for x in gs), gs
+        for name, fid in (("vel", L.FIELD_VELOCITY), ("dye", L.FIELD_DENSITY), ("p", L.FIELD_PRESSURE)):
+            a = g.field(name)
+            assert np.array_equal(a, s.read_field(fid)), name
+            assert np.abs(a).max() > 0
     finally:
         g.close()
         s.close()

@@ -52,7 +52,7 @@ GPU_CASES = {
 def test_hip_slabs_equal_oracle(tmp_path, oracle_omp, world, name):
     import test_slabs as T
     case = GPU_CASES[name]
-    mp.spawn(_worker, args=(world, T._free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    T._spawn(_worker, world, case, str(tmp_path))
     vel, dye, prs = T._reference(case)
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
