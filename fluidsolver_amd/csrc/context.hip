@@ -167,6 +167,73 @@ static int st_particles(fs_ctx *c)
                                  c->part[3], c->part[4], c->part[5], c->part[6], c->stream);
 }
 
+// ---- tracer order (one GPU): see passes.hip "Tracer order" ------------------------------------------------------
+static int ensure_part_t(fs_ctx *c)
+{
+    bool all = true;
+    for (int i = 0; i < 7; ++i) all = all && c->part_t[i];
+    if (all) return FS_OK;
+    for (int i = 0; i < 7; ++i) {
+        if (c->part_t[i]) continue;
+        hipError_t e = hipMalloc((void **)&c->part_t[i], (size_t)c->max_particles * sizeof(float));
+        if (e != hipSuccess) {   // all or nothing: a later call must not find half of the planes
+            for (int k = 0; k < 7; ++k) { (void)hipFree(c->part_t[k]); c->part_t[k] = nullptr; }
+            return fs::hip_fail(e, "hipMalloc(tracer partner arrays)");
+        }
+    }
+    return FS_OK;
+}
+// back to slot order: every call that shows the arrays to the host, or relies on their age order, comes through here
+static int tracer_restore_order(fs_ctx *c)
+{
+    if (!c->part_sorted) return FS_OK;
+    c->part_sorted = false;
+    c->frames_since_sort = 1 << 20;   // sorted again by the next update
+    if (c->n_particles > 0) {
+        int rc = fs::tracer_unsort(c->n_particles, c->part, c->part_t, c->part_perm, c->stream);
+        if (rc) return rc;
+        for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+        c->part_flip ^= 1;
+    }
+    return FS_OK;
+}
+// called once per tracer update, before it is enqueued (never under stream capture: it allocates on first use)
+static int tracer_maybe_sort(fs_ctx *c)
+{
+    if (c->world > 1 || c->sort_every <= 0 || c->n_particles < 16384) return FS_OK;
+    if (++c->frames_since_sort < c->sort_every) return FS_OK;
+    int nbx, shift;
+    const long nbins = (fs::tracer_bins(&c->grid, &nbx, &shift) + 3) & ~3;   // (the scan reads and writes quads)
+    int rc = ensure_part_t(c);
+    if (rc) return rc;
+    if (c->sort_cap < c->max_particles) {
+        (void)hipFree(c->part_perm); (void)hipFree(c->part_perm_t); (void)hipFree(c->sort_keys);
+        c->part_perm = c->part_perm_t = c->sort_keys = nullptr;
+        c->sort_cap = 0;
+        c->part_sorted = false;   // (only reached with the arrays in slot order: the capacity changes through fs_particles_reserve)
+        FS_HIP(hipMalloc((void **)&c->part_perm, (size_t)c->max_particles * sizeof(int)));
+        FS_HIP(hipMalloc((void **)&c->part_perm_t, (size_t)c->max_particles * sizeof(int)));
+        FS_HIP(hipMalloc((void **)&c->sort_keys, (size_t)c->max_particles * sizeof(int)));
+        c->sort_cap = c->max_particles;
+    }
+    if (c->sort_hist_cap < nbins) {
+        (void)hipFree(c->sort_hist);
+        c->sort_hist = nullptr; c->sort_hist_cap = 0;
+        FS_HIP(hipMalloc((void **)&c->sort_hist, (size_t)nbins * sizeof(int)));
+        c->sort_hist_cap = nbins;
+    }
+    rc = fs::tracer_sort(&c->grid, &c->pparams, c->n_particles, c->part, c->part_t, c->sort_keys, c->sort_hist,
+                         c->part_sorted ? c->part_perm : nullptr, c->part_perm_t, c->stream);
+    if (rc) return rc;
+    for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+    std::swap(c->part_perm, c->part_perm_t);
+    c->part_flip ^= 1;
+    c->part_sorted = true;
+    c->frames_since_sort = 0;
+    c->stat_sorts += 1;
+    return FS_OK;
+}
+
 // ---- staging area of fs_particle_lines_static (the entry point that allocates nothing) ----------------------
 // A file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the
 // process ends (5 MiB).  In host code the array's NAME is only a stand-in for the symbol, never a device
@@ -279,7 +346,8 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
         e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(particles)");
     }
-    if (!rc) rc = scratch_for_device(device, &c->lines_scratch);
+    // (the staging area only serves fs_particle_lines_static, which reports its absence itself: not a reason to fail a context)
+    if (!rc && scratch_for_device(device, &c->lines_scratch)) { c->lines_scratch = nullptr; (void)hipGetLastError(); }
     if (rc) { fs_destroy(c); return rc; }
     rc = fs_reset(c);
     if (rc) { fs_destroy(c); return rc; }
@@ -345,6 +413,7 @@ int fs_destroy(fs_ctx *c)
     if (c->cfl_host) (void)hipHostFree(c->cfl_host);
     for (int i = 0; i < 7; ++i) { (void)hipFree(c->part[i]); (void)hipFree(c->part_t[i]); (void)hipFree(c->outbox[i]); }
     (void)hipFree(c->tr_counts_dev); (void)hipFree(c->tr_matrix_dev); (void)hipFree(c->spawn_sums);
+    (void)hipFree(c->part_perm); (void)hipFree(c->part_perm_t); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_hist);
     if (c->tr_counts_host) (void)hipHostFree(c->tr_counts_host);
     if (c->tr_matrix_host) (void)hipHostFree(c->tr_matrix_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -457,6 +526,12 @@ int fs_set_option(fs_ctx *c, int option, int value)
         break;
     case FS_OPT_SPLIT_PLANES: changed = set(c->split_planes, value ? 1 : 0); break;
     case FS_OPT_SPLIT_ROWS: changed = set(c->split_rows, value ? 1 : 0); break;
+    case FS_OPT_TRACER_SORT:
+        if (value < 0) { fs::set_error("FS_OPT_TRACER_SORT: negative interval"); return ctx_fail(c, FS_ERR_INVALID); }
+        c->sort_every = value;
+        c->frames_since_sort = 1 << 20;
+        changed = false;
+        break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     if (changed) drop_graphs(c);   // (a value that is already in force keeps the recorded frames)
@@ -505,6 +580,7 @@ int fs_step(fs_ctx *c)
         return FS_OK;
     }
     fs::ensure_band_planes(c, c->params.solverIterations);
+    if (c->with_particles && c->n_particles > 0) TRY(c, tracer_maybe_sort(c));
     struct Mark { fs_ctx *c; ~Mark() { c->p_band_dirty = c->p_band_active; } } mark{c};   // after the frame, however it ran
     // Scalars are baked into the recorded kernel nodes, so a change of parameters invalidates the graphs.  A host
     // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
@@ -517,7 +593,8 @@ int fs_step(fs_ctx *c)
     // (from here on a change of values costs one host-side recording per ping-pong state and no instantiation)
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph
     // is keyed by the ping-pong state it was recorded from.
-    const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3);
+    const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3) |
+                                   ((unsigned long long)(c->with_particles ? c->part_flip : 0) << 62);   // (which of the two sets of tracer arrays)
     auto it = c->graphs.find(key);
     if (it != c->graphs.end() && c->graphs_epoch[key] == c->param_epoch) {
         TRYHIP(c, hipGraphLaunch(it->second, c->stream));
@@ -719,6 +796,10 @@ int fs_particles_reserve(fs_ctx *c, long capacity)
     }
     c->n_particles = 0;
     c->max_particles = 0;
+    c->part_sorted = false;
+    (void)hipFree(c->part_perm); (void)hipFree(c->part_perm_t); (void)hipFree(c->sort_keys);
+    c->part_perm = c->part_perm_t = c->sort_keys = nullptr;
+    c->sort_cap = 0;
     drop_graphs(c);
     for (int i = 0; i < 7 && capacity > 0; ++i) {
         TRYHIP(c, hipMalloc((void **)&c->part[i], (size_t)capacity * sizeof(float)));
@@ -760,6 +841,7 @@ int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const 
     const long mine = hi - lo;
     if (mine > c->max_particles) { fs::set_error("particle count %ld exceeds capacity %ld", mine, c->max_particles); return ctx_fail(c, FS_ERR_INVALID); }
     const float *src[7] = {px, py, vx, vy, life, mass, age};
+    TRY(c, tracer_restore_order(c));   // (tracers beyond the new ones keep their slots)
     TRYHIP(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 7 && mine > 0; ++i) {
         if (!src[i]) { fs::set_error("NULL particle array %d", i); return ctx_fail(c, FS_ERR_INVALID); }
@@ -777,6 +859,7 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
     TRY(c, fs::settle(c));
     if (n < 0 || n > c->n_particles) { fs::set_error("asked for %ld of %ld particles", n, c->n_particles); return ctx_fail(c, FS_ERR_INVALID); }
     float *dst[7] = {px, py, vx, vy, life, mass, age};
+    TRY(c, tracer_restore_order(c));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 7 && n > 0; ++i)
         if (dst[i]) TRYHIP(c, hipMemcpy(dst[i], c->part[i], (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
@@ -796,12 +879,12 @@ int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, un
     if (count < 0) { fs::set_error("negative spawn count"); return ctx_fail(c, FS_ERR_INVALID); }
     const long cap = c->max_particles, n = c->n_particles;
     if (cap == 0) return FS_OK;   // (count == 0 still drops the dead slots: the reference's array never holds any)
-    if (!c->part_t[0])
-        for (int i = 0; i < 7; ++i) TRYHIP(c, hipMalloc((void **)&c->part_t[i], (size_t)cap * sizeof(float)));
+    TRY(c, ensure_part_t(c));
+    TRY(c, tracer_restore_order(c));   // the slots are in age order, which decides who is dropped at the cap
     const long nb = fs::tracer_blocks(cap);
     if (c->spawn_sums_cap < nb + 1) {
         (void)hipFree(c->spawn_sums);
-        c->spawn_sums = nullptr; c->spawn_sums_cap = 0;
+        c->spawn_sums = nullptr; c->spawn_sums_cap = 0;   // (a failed allocation below leaves "none", not a stale size)
         TRYHIP(c, hipMalloc((void **)&c->spawn_sums, (size_t)(nb + 1) * sizeof(int)));
         c->spawn_sums_cap = nb + 1;
     }
@@ -820,6 +903,7 @@ int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, un
     const long j0 = std::max(0L, count - cap);                        // more new tracers than slots: the first ones are pushed out too
     TRY(c, fs::tracer_spawn(kept, j0, count, c->part_t, x, y, radius, seed, c->stream));
     for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+    c->part_flip ^= 1;
     c->n_particles = after;
     if (c->with_particles) drop_graphs(c);   // array pointers and the count are baked into the tracer node
     return FS_OK;
@@ -832,6 +916,7 @@ int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particl
     const long n = c->n_particles;
     if (n == 0) return FS_OK;
     if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
+    TRY(c, tracer_restore_order(c));
     float *xy = nullptr, *al = nullptr;
     TRYHIP(c, hipMalloc((void **)&xy, (size_t)n * 5 * sizeof(float)));
     al = xy + 4 * n;
@@ -861,6 +946,7 @@ int fs_particle_lines_static(fs_ctx *c, float viewportW, float viewportH, float 
                       "use fs_particle_lines", n, FS_LINES_STATIC_MAX);
         return ctx_fail(c, FS_ERR_INVALID);
     }
+    TRY(c, tracer_restore_order(c));   // (allocates nothing: the partner arrays exist whenever the order is not the slots')
     float *xy = c->lines_scratch;
     if (!xy) { fs::set_error("fs_particle_lines_static: no staging area on device %d", c->device); return ctx_fail(c, FS_ERR_STATE); }
     float *al = xy + 4 * n;
@@ -880,6 +966,7 @@ int fs_particles_update(fs_ctx *c, const fs_particle_params *pp)
         if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
     }
     if (c->n_particles == 0) return FS_OK;   // Part:243 guard
+    TRY(c, tracer_maybe_sort(c));
     TRY(c, st_particles(c));
     return FS_OK;
 }

@@ -187,6 +187,14 @@ struct fs_ctx {
     int *tr_matrix_host = nullptr;      // pinned
     std::vector<long> tr_send_off, tr_recv_cnt;
     long stat_migrated = 0;
+    // tracer order (one GPU): the arrays are kept sorted by the cache line their velocity lookup reads (passes.hip)
+    int sort_every = 32;                // FS_OPT_TRACER_SORT: frames between two sorts (0 = never)
+    int frames_since_sort = 1 << 20;
+    bool part_sorted = false;           // part[] is in sorted order; part_perm[i] = slot tracer i came from
+    int part_flip = 0;                  // toggles with every part <-> part_t swap (part of the frame graphs' key)
+    int *part_perm = nullptr, *part_perm_t = nullptr, *sort_keys = nullptr, *sort_hist = nullptr;
+    long sort_cap = 0, sort_hist_cap = 0;
+    long stat_sorts = 0;
     int *spawn_sums = nullptr;          // fs_particles_spawn: live counts per block of 256 slots, then their scan (blocks + 1 ints)
     long spawn_sums_cap = 0;
     float *lines_scratch = nullptr;     // this device's copy of the static staging array (fs_particle_lines_static); not owned
@@ -199,6 +207,11 @@ namespace fs {
 int ctx_fail(fs_ctx *c, int rc);
 fs_grid grid_of(const fs_ctx *c, int depth);
 
+// tracer order (passes.hip)
+int tracer_bins(const fs_grid *g, int *nbx, int *shift);
+int tracer_sort(const fs_grid *g, const fs_particle_params *pp, long n, float *const in[7], float *const out[7], int *keys, int *hist,
+                const int *perm_in, int *perm_out, hipStream_t st);
+int tracer_unsort(long n, float *const in[7], float *const out[7], const int *perm, hipStream_t st);
 // tracer spawning (passes.hip)
 long tracer_blocks(long n);
 int tracer_count_live(long n, const float *life, int *sums, hipStream_t st);

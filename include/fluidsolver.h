@@ -294,6 +294,8 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      applied since repeated -- runs at the start of the next call on the context that is not
                                      fs_add_force (fs_step, fs_sync, a read, fs_slab_info ...), where FS_ERR_HALO is then reported.
                                      0 = fs_step waits for the bound itself (one device round trip per frame) */
+       FS_OPT_TRACER_SORT = 18,   /* one GPU: frames between two re-orderings of the tracer arrays by the cache line their velocity lookup
+                                     reads (default 32; 0 = never).  Invisible outside: every call that exposes slot order restores it */
        FS_OPT_SLAB_SERIALIZE = 17, /* local groups only, a measurement aid (set it on EVERY slab of the group): 1 = the K slabs, which share
                                      one GPU there, run their launches one slab after the other instead of side by side, so that the
                                      group's frame takes K x what one slab's frame takes on a GPU of its own (scripts/time_slabs.py) */

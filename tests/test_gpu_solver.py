@@ -749,6 +749,62 @@ def test_config3_full_size_matches_oracle(oracle_omp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_graph", [False, True])
+def test_tracer_sort_is_invisible(in_graph):
+    # FS_OPT_TRACER_SORT: the tracer arrays are re-ordered by the cache line their lookup reads every few frames (here
+    # every 3rd), and every call that exposes slot order restores it.  Against the same run with the sort off: all seven
+    # arrays after every kind of access in mid-run -- get, line vertices, spawning at the cap (age order decides who is
+    # dropped), a partial fs_particles_set -- and at the end, by slot, bit for bit.
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    from fluidsolver_amd.script import splat
+    W, H, n, cap = 768, 640, 60000, 64000
+    rng = np.random.default_rng(11)
+    z = np.zeros(n, F)
+    arrs = [rng.uniform(0, W, n).astype(F), rng.uniform(0, H, n).astype(F), z, z.copy(),
+            rng.uniform(0.3, 1.0, n).astype(F), rng.uniform(0.1, 1.0, n).astype(F), z.copy()]
+    arrs[4][::7] = 0.0   # dead slots stay where they are
+    runs = []
+    for every in (3, 0):
+        s = FluidSolver(W, H, max_particles=cap)
+        (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 12)
+        s.displayMode = None
+        s.set_option(L.OPT_TRACER_SORT, every)
+        ps = ParticleSystem(s)
+        ps.fluidForce, ps.linkToViscosity = 2.0, False
+        ps.set_arrays(*arrs)
+        if in_graph:
+            ps.stepWithSolver((W, H))
+        seen = []
+        try:
+            for f in range(24):
+                pos, force, col = splat(W, H, 6 * f + 1)
+                s.applyForce(pos, force, col)
+                s.update()
+                if not in_graph:
+                    ps.update(s, (W, H))
+                if f == 5:
+                    seen.append(ps.get_arrays())
+                if f == 8:
+                    seen.append(list(ps.lineVertices((W, H), 1.5)))
+                if f in (10, 11, 17):
+                    ps.addParticles((300.0 + f, 200.0), count=3000, seed=77 + f)     # 60000 + 9000 > cap: the oldest go
+                if f == 14:
+                    k = 30000
+                    L.check(s._lib.fs_particles_set(s.ctx, k, *[a[:k].ctypes.data_as(C.c_void_p) for a in arrs]), s.ctx)
+                    seen.append([np.array([ps.particleCount], F)])
+            s.sync()
+            seen.append(ps.get_arrays())
+            runs.append(seen)
+        finally:
+            s.close()
+    for a, b in zip(*runs):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert (runs[0][-1][2] != 0).any() and len(runs[0][-1][0]) > 16384   # (still above the size below which nothing is sorted)
+
+
+@pytest.mark.gpu
 def test_jacobi_tuning_is_per_context():
     # two contexts in one process: fs_set_option on one (block depth, tile shape) leaves the other's launches alone
     # (they used to share process-wide statics), and both still produce the same bits
