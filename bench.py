@@ -81,6 +81,14 @@ def start_watchdog():
     threading.Thread(target=bark, daemon=True).start()
 
 
+def ctx_option(s, key):
+    """An option as the context of `s` (FluidSolver or slab) runs it -- not the process default."""
+    from fluidsolver_amd import lib as L
+    v = C.c_int()
+    L.check(L.load().fs_get_option(s.ctx, key, C.byref(v)), s.ctx)
+    return v.value
+
+
 def make_single(W, H, params, particles):
     from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
     s = FluidSolver(W, H, max_particles=particles)
@@ -122,7 +130,7 @@ def jacobi_microbench(s, W, H, sweeps=40, reps=25):
     lib.fs_harness_fill_uniform(div.ctypes.data_as(C.c_void_p), div.size, -1.0, 1.0, 1234)
     s.write_field(L.FIELD_DIVERGENCE, div)
     s.write_field(L.FIELD_PRESSURE, np.zeros((1, H, W), np.float32))
-    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE)
+    depth = ctx_option(s, L.OPT_BLOCK_DEPTH_PRESSURE)   # (fs_stage runs the context's tuning)
     s.stage(L.STAGE_PRESSURE_CLEARED, sweeps)   # warm-up
     s.sync()
     ms = C.c_float()
@@ -142,7 +150,7 @@ def diffuse_microbench(s, W, H, sweeps=40, reps=10):
     vel = np.empty((2, H, W), np.float32)
     lib.fs_harness_fill_uniform(vel.ctypes.data_as(C.c_void_p), vel.size, -1.0, 1.0, 4321)
     s.write_field(L.FIELD_VELOCITY, vel)
-    depth = lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE)
+    depth = ctx_option(s, L.OPT_BLOCK_DEPTH_DIFFUSE)
     s.stage(L.STAGE_DIFFUSE_VELOCITY, sweeps)   # warm-up
     s.sync()
     ms = C.c_float()
@@ -482,8 +490,8 @@ def main():
         "data": "synthetic (scripted Lissajous splats, SURVEY 8(d); zero initial state)",
         "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "grid": [W, H],
                    "solverIterations": params[5], "particles": wl["particles"], "parallelism": parallelism,
-                   "jacobi_block_depth": {"pressure": lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE),
-                                          "diffuse": lib.fs_config_get(L.OPT_BLOCK_DEPTH_DIFFUSE)}},
+                   "jacobi_block_depth": {"pressure": ctx_option(s, L.OPT_BLOCK_DEPTH_PRESSURE),
+                                          "diffuse": ctx_option(s, L.OPT_BLOCK_DEPTH_DIFFUSE)}},
         "frames_per_s": fps,
         "host_enqueue_us_per_frame": t_enq * 1e6 / args.steps,
     }

@@ -463,6 +463,7 @@ int fs_reset(fs_ctx *c)
     TRYHIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
     for (int &h : c->halo_hist) h = -1;
     c->p_band_dirty = false;
+    c->vort_stale = false;
     return FS_OK;
 }
 
@@ -535,6 +536,30 @@ int fs_set_option(fs_ctx *c, int option, int value)
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     if (changed) drop_graphs(c);   // (a value that is already in force keeps the recorded frames)
+    return FS_OK;
+}
+
+int fs_get_option(fs_ctx *c, int option, int *value)
+{
+    if (!c || !value) { fs::set_error("fs_get_option: NULL argument"); return FS_ERR_INVALID; }
+    switch (option) {
+    case FS_OPT_USE_GRAPH: *value = c->use_graph; break;
+    case FS_OPT_BLOCK_DEPTH: case FS_OPT_BLOCK_DEPTH_PRESSURE: case FS_OPT_BLOCK_DEPTH_DIFFUSE:
+    case FS_OPT_TILE_VARIANT: case FS_OPT_TILE_VARIANT_DIFFUSE: case FS_OPT_STAGGER: case FS_OPT_STAGGER_MODE: case FS_OPT_BAND_DELAY:
+        *value = fs::tuning_get(c->tuning, option);
+        break;
+    case FS_OPT_WITH_PARTICLES: *value = c->with_particles; break;
+    case FS_OPT_FUSE: *value = c->fuse; break;
+    case FS_OPT_SLAB_OVERLAP: *value = c->overlap; break;
+    case FS_OPT_SLAB_PROFILE: *value = c->profile; break;
+    case FS_OPT_SLAB_DEFER: *value = c->defer_check; break;
+    case FS_OPT_SEGMENT_GRAPH_AFTER: *value = c->seg_min_stable; break;
+    case FS_OPT_SLAB_SERIALIZE: *value = c->comm ? c->comm->serialize : 0; break;
+    case FS_OPT_SPLIT_PLANES: *value = c->split_planes; break;
+    case FS_OPT_SPLIT_ROWS: *value = c->split_rows; break;
+    case FS_OPT_TRACER_SORT: *value = c->sort_every; break;
+    default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
+    }
     return FS_OK;
 }
 
@@ -690,6 +715,14 @@ static int copy_field(fs_ctx *c, int field, float *host, size_t bytes, bool to_h
     const size_t need = (size_t)np * c->W * rows * sizeof(float);
     if (bytes != need) { fs::set_error("%s: expected %zu bytes, got %zu", who, need, bytes); return ctx_fail(c, FS_ERR_INVALID); }
     if (field == FS_FIELD_PRESSURE) TRY(c, settle_pressure(c));
+    if (field == FS_FIELD_VORTICITY && to_host && c->vort_stale) {
+        // (the reference's vorticity texture holds the curl of the velocity update() started from: not something that can
+        // be recomputed from the fields a finished frame leaves)
+        fs::set_error("%s: the last frame computed curl and confinement in one pass and did not write the vorticity plane; "
+                      "FS_OPT_FUSE 0, the vorticity display mode or fs_stage keep it", who);
+        return ctx_fail(c, FS_ERR_STATE);
+    }
+    if (field == FS_FIELD_VORTICITY && !to_host) c->vort_stale = false;
     TRYHIP(c, hipStreamSynchronize(c->stream));
     float *dev = field_ptr(c, field) + (size_t)(c->r0 - c->b0) * c->pitch;
     const size_t hp = (size_t)c->W * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
@@ -762,7 +795,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
     float *u = c->f[F_VEL].p(), *v = u + c->plane;
     int rc;
     switch (stage) {
-    case FS_STAGE_VORTICITY: rc = fs_k_calculateVorticity(&c->grid, u, v, c->f[F_VORT].p(), c->stream); break;      // Solver:488-491
+    case FS_STAGE_VORTICITY: rc = fs_k_calculateVorticity(&c->grid, u, v, c->f[F_VORT].p(), c->stream); c->vort_stale = false; break;   // Solver:488-491
     case FS_STAGE_APPLY_VORTICITY:
         rc = fs_k_applyVorticity(&c->grid, c->f[F_VORT].p(), u, v, c->params.vorticityStrength, c->params.deltaTime, c->stream);   // :494-501
         break;

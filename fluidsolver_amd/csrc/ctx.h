@@ -145,6 +145,7 @@ struct fs_ctx {
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
     bool p_zero = false;                // planner state: pressure iterate is implicitly 0
+    bool vort_stale = false;            // the last frame computed curl + confinement in one pass: the vorticity plane was not written
     std::vector<fs::Step> steps;
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
     std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves

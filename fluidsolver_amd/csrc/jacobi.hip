@@ -672,6 +672,7 @@ int tuning_get(const JacobiTuning &t, int key)
     case FS_OPT_TILE_VARIANT: return t.variant[0];
     case FS_OPT_TILE_VARIANT_DIFFUSE: return t.variant[1];
     case FS_OPT_STAGGER: return t.stagger;
+    case FS_OPT_STAGGER_MODE: return t.stagger_mode;
     case FS_OPT_BAND_DELAY: return t.band_delay;
     }
     return FS_ERR_INVALID;

@@ -365,7 +365,9 @@ struct Planner {
                 const float strength = p.vorticityStrength;
                 compute("vorticity_apply", g, 0, [=]() { return fs_k_vorticity_apply(&g, u, v, uo, vo, strength, dt, st); });   // :486-502
                 V.flip();
+                c->vort_stale = true;
             } else {
+                c->vort_stale = false;
                 {
                     const fs_grid g = grid_of(c, dw);
                     float *u = V.p(), *v = off(u, plane), *w = c->f[F_VORT].p();

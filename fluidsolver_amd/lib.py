@@ -93,6 +93,7 @@ SIGNATURES = {
     "fs_set_params": (_i, [_p, C.POINTER(Params)]),
     "fs_get_params": (_i, [_p, C.POINTER(Params)]),
     "fs_set_option": (_i, [_p, _i, _i]),
+    "fs_get_option": (_i, [_p, _i, C.POINTER(_i)]),
     "fs_add_force": (_i, [_p, _f, _f, _f, _f, C.POINTER(_f), _f, _f]),
     "fs_step": (_i, [_p]),
     "fs_sync": (_i, [_p]),

@@ -151,6 +151,12 @@ class FluidSolver:
     def set_option(self, option, value):
         L.check(self._lib.fs_set_option(self._ctx, option, int(value)), self._ctx)
 
+    def get_option(self, option):
+        """What THIS context runs with (fs_config_get reads the process-wide default a new context starts from)."""
+        v = C.c_int()
+        L.check(self._lib.fs_get_option(self._ctx, option, C.byref(v)), self._ctx)
+        return v.value
+
     def stage(self, stage, n=0):
         p = self._params()
         L.check(self._lib.fs_set_params(self._ctx, C.byref(p)), self._ctx)

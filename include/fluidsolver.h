@@ -256,7 +256,9 @@ typedef struct fs_params {
 enum { FS_DISPLAY_NONE = -1, FS_DISPLAY_DENSITY = 0, FS_DISPLAY_VELOCITY = 1, FS_DISPLAY_SPEED = 2,
        FS_DISPLAY_VORTICITY = 3, FS_DISPLAY_PARTICLES_ONLY = 4 };
 
-/* Intermediate planes are only as current as the frame plan keeps them: with FS_OPT_FUSE != 0 fs_step computes the
+/* fs_read_field(FS_FIELD_VORTICITY) after a frame that computed curl and confinement in one pass (the default on grids at
+ * least 512 wide) returns FS_ERR_STATE instead of an old plane.
+ * Intermediate planes are only as current as the frame plan keeps them: with FS_OPT_FUSE != 0 fs_step computes the
  * vorticity in registers on grids at least 512 wide (FS_FIELD_VORTICITY is then not updated, except in the vorticity
  * display mode), and the divergence of the domain's outermost ring may be skipped by the fused projection.  Velocity,
  * density, pressure and display always hold the reference's values.  FS_OPT_FUSE = 0 or fs_stage keep every plane. */
@@ -317,6 +319,7 @@ int fs_default_params(fs_params *p);                         /* defaults of Solv
 int fs_set_params(fs_ctx *ctx, const fs_params *p);
 int fs_get_params(fs_ctx *ctx, fs_params *p);
 int fs_set_option(fs_ctx *ctx, int option, int value);   /* the tuning keys of fs_config_set change THIS context's copy only */
+int fs_get_option(fs_ctx *ctx, int option, int *value);  /* what THIS context runs with (fs_config_get reads the process default) */
 
 /* applyForce(position:force:color:), Solver:444-470, in GRID units (the 5 addForces
  * arguments; color alpha is accepted for signature parity and ignored). */
@@ -332,7 +335,11 @@ int fs_read_field(fs_ctx *ctx, int field, float *host, size_t bytes);
 int fs_write_field(fs_ctx *ctx, int field, const float *host, size_t bytes);
 
 /* Zero-copy view for hosts that already live on the device (benchmarks, torch):
- * device pointer of plane `plane` of the field's CURRENT ping-pong side. */
+ * device pointer of plane `plane` of the field's CURRENT ping-pong side.  The pointer is good until the next fs_step /
+ * fs_stage / fs_write_field on the context (the sides swap, Solver:516,:540,:558,:584) and its contents are complete
+ * once fs_sync has returned: for the pressure in particular the rows a two-band projection (FS_OPT_SPLIT_ROWS) left in
+ * the band's private plane are copied home by THIS call, asynchronously on the context's stream -- a host that keeps the
+ * pointer across frames, or reads it from a stream of its own without fs_sync, sees the lower rows of an older frame. */
 int fs_field_device_ptr(fs_ctx *ctx, int field, int plane, void **dev_ptr, int *pitch);
 void *fs_stream(fs_ctx *ctx);
 

@@ -278,6 +278,34 @@ def test_update_boundary_invariants():
             assert not s.read_field(f)[0][sl].any()
 
 
+def test_vorticity_plane_is_refused_when_the_frame_did_not_write_it(oracle):
+    """On grids at least 512 wide fs_step computes curl + confinement in one pass and never writes the vorticity plane:
+    fs_read_field must say so (FS_ERR_STATE) instead of handing out an old plane; FS_OPT_FUSE 0 keeps the plane, and it
+    equals the oracle's; fs_get_option reports what the context runs with."""
+    from fluidsolver_amd import lib as L
+    from oracle_binding import VORTICITY, Params
+    W, H, params = 600, 96, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 6)
+    s = make_solver(W, H, params)
+    o = oracle.solver(W, H)
+    try:
+        assert s.get_option(L.OPT_FUSE) == 1 and s.get_option(L.OPT_BLOCK_DEPTH_PRESSURE) == L.load().fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE)
+        s.applyForce((300.0, 40.0), (30.0, -12.0), (100.0, 40.0, 5.0))
+        o.add_force((300.0, 40.0), (30.0, -12.0), (100.0, 40.0, 5.0), 5.0, 0.5)
+        s.update()
+        o.update(Params(*params))
+        with pytest.raises(L.FluidSolverError) as e:
+            s.read_field(L.FIELD_VORTICITY)
+        assert e.value.code == -5 and "vorticity" in str(e.value)
+        s.set_option(L.OPT_FUSE, 0)
+        s.set_option(L.OPT_BLOCK_DEPTH_PRESSURE, 3)
+        assert s.get_option(L.OPT_FUSE) == 0 and s.get_option(L.OPT_BLOCK_DEPTH_PRESSURE) == 3
+        s.update()
+        o.update(Params(*params))
+        assert np.array_equal(s.read_field(L.FIELD_VORTICITY), o.field(VORTICITY))
+    finally:
+        s.close()
+
+
 def test_stage_calls_equal_update(oracle):
     """fs_stage() per reference kernel == fs_step(): a host can drive the stages itself."""
     from fluidsolver_amd import lib as L
@@ -578,11 +606,11 @@ def test_config2_fifty_frames_match_oracle(oracle_omp):
 
 def test_config4_grid_frames_match_oracle(oracle_omp):
     """The largest configured grid (BASELINE config 4: 16384^2, N = 40, eight scripted pointers) on one GPU, two
-    frames: every plane is 1 GiB, nothing fits the Infinity Cache, the frame runs the out-of-cache plan.  Velocity and
-    dye bit-identical to the (OpenMP) oracle."""
+    frames: every plane is 1 GiB, nothing fits the Infinity Cache, the frame runs the out-of-cache plan.  Velocity,
+    dye and pressure bit-identical to the (OpenMP) oracle."""
     from fluidsolver_amd import lib as L
     from fluidsolver_amd.script import splat
-    from oracle_binding import DENSITY, VELOCITY, Params
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
     W = H = 16384
     params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 40)
     s = make_solver(W, H, params)
@@ -595,9 +623,37 @@ def test_config4_grid_frames_match_oracle(oracle_omp):
             o.add_force(pos, force, col, 5.0, 0.5)
         s.update()
         o.update(p)
-    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY)):
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
         got = s.read_field(fg)
         assert np.array_equal(got, o.field(fo)), fg
+        assert np.abs(got).max() > 0
+        del got
+    s.close()
+
+
+def test_config5_step_matches_oracle(oracle_omp):
+    """BASELINE config 5's own step on one GPU: 8192^2 with N = 100 (eight launches per pressure loop, thirteen per
+    diffuse loop, the out-of-cache plan), two frames of two scripted pointers: velocity, dye and pressure bit-identical
+    to the (OpenMP) oracle.  (The slab form of the same step is compared with this context in test_gpu_native_slabs.py.)"""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.script import splat
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W = H = 8192
+    params = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 100)
+    s = make_solver(W, H, params)
+    o = oracle_omp.solver(W, H)
+    p = Params(*params)
+    for f in (1, 2):
+        for ptr in range(2):
+            pos, force, col = splat(W, H, 5 * f, ptr, 2)
+            s.applyForce(pos, force, col)
+            o.add_force(pos, force, col, 5.0, 0.5)
+        s.update()
+        o.update(p)
+    for fg, fo in ((L.FIELD_VELOCITY, VELOCITY), (L.FIELD_DENSITY, DENSITY), (L.FIELD_PRESSURE, PRESSURE)):
+        got = s.read_field(fg)
+        assert np.array_equal(got, o.field(fo)), fg
+        assert np.abs(got).max() > 0
         del got
     s.close()
 

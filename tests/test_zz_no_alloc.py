@@ -42,7 +42,11 @@ def test_static_lines_equal_allocating_entry_point(oracle):
             arrs = _tracers(n, seed, W, H)
             ps.set_arrays(*arrs)
             exy, ealpha = _lines(lib, L, s, lib.fs_particle_lines, n, view, scale)
+            import torch
+            free_before = torch.cuda.mem_get_info()[0]
             gxy, galpha = _lines(lib, L, s, lib.fs_particle_lines_static, n, view, scale)
+            # "allocates nothing": the device's free memory is the same after the call as before it
+            assert torch.cuda.mem_get_info()[0] == free_before
             assert np.array_equal(gxy, exy) and np.array_equal(galpha, ealpha)
             oxy, oalpha = oracle.particle_lines(*arrs[:5], view, scale)
             assert np.array_equal(gxy, oxy.reshape(n, 4)) and np.array_equal(galpha, oalpha)
