@@ -180,6 +180,24 @@ __device__ __forceinline__ void sweep_once(const Row (&src)[R], Row (&dst)[R], c
     const Row below = row_of(xch[buf][wdn][0][lane]);    // row below it
     dst[0] = fix(sweep_row<OP>(src[0], above, R > 1 ? src[1] : below, d[0], a, rden), src[0], 0);
     if (R > 1) dst[R - 1] = fix(sweep_row<OP>(src[R - 1], src[R - 2], below, d[R - 1], a, rden), src[R - 1], R - 1);
+#ifdef FS_PROBE_GUARD   // timing experiment only: what a wave-level range guard of the fast division would cost per sweep
+    if (OP == OP_DIFFUSE) {
+        // smallest |value| and the OR of all bits of the lane's R x 4 results: one v_min3_f32 with |.| modifiers and one v_or3_b32
+        // per two values; the wave takes the exact path when a lane holds a non-zero value below 2^-96 (or any zero beside
+        // non-zeros, which the minimum cannot tell from a tiny value)
+        float mn = 0x1p100f;
+        unsigned orb = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(mn) : "v"(dst[i].a.x), "v"(dst[i].a.y));
+            asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(mn) : "v"(dst[i].b.x), "v"(dst[i].b.y));
+            asm("v_or3_b32 %0, %0, %1, %2" : "+v"(orb) : "v"(dst[i].a.x), "v"(dst[i].a.y));
+            asm("v_or3_b32 %0, %0, %1, %2" : "+v"(orb) : "v"(dst[i].b.x), "v"(dst[i].b.y));
+        }
+        const bool ok = mn >= 0x1p-96f || (orb << 1) == 0u;
+        if (__ballot(!ok) != 0ull && lane == 0) xch[buf][wave][0][0].x += 0.0f;   // (stands in for the branch to the exact path)
+    }
+#endif
 }
 
 // T sweeps on the register tile.  Diffuse: two per trip, ping-ponging between p and a second register tile q.
@@ -694,6 +712,34 @@ __global__ __launch_bounds__(256) void k_selftest_divide(float den, double rden,
     if (bad) atomicAdd(mismatches, bad);
 }
 
+#ifdef FS_PROBE
+// Probe build only: how often does the three-instruction fp32 form  q0 = RN(x r), n = fma(q0, den, -x), q = fma(-n, r, q0)
+// with r = RN(1 / den)  (Markstein; "division by a constant known in advance") differ from the IEEE quotient?  All 2^32
+// bit patterns of x; counted apart for x inside [2^-100, 2^100] (no intermediate can underflow or overflow there) and outside.
+__global__ __launch_bounds__(256) void k_selftest_divide_fast(float den, float r, unsigned long long *out)
+{
+    unsigned long long bad_in = 0, bad_out = 0;
+    unsigned first = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((unsigned)i);
+        const float q = x / den;
+        const float q0 = x * r;
+        const float n = __builtin_fmaf(q0, den, -x);
+        const float f = __builtin_fmaf(-n, r, q0);
+        const bool same = (q != q && f != f) || __float_as_uint(q) == __float_as_uint(f);
+        if (!same) {
+            const float ax = fabsf(x);
+            if (ax >= 0x1p-100f && ax <= 0x1p100f) { bad_in += 1; if (!first) first = (unsigned)i; }
+            else bad_out += 1;
+        }
+    }
+    if (bad_in) atomicAdd(&out[0], bad_in);
+    if (bad_out) atomicAdd(&out[1], bad_out);
+    if (first) atomicMax(&out[2], (unsigned long long)first);
+}
+#endif
+
 static void diffuse_coeffs(const fs_grid *g, float viscosity, float dt, float *a, float *den)
 {
     // Shaders:96  a = deltaTime * viscosity * width * height  (uint -> float)
@@ -843,6 +889,21 @@ int fs_probe_timeline(unsigned long long *host, long nwords)   // probe build on
     if (!host || nwords < 0 || nwords > 8L * FS_TL_MAX) return FS_ERR_INVALID;
     FS_HIP(hipDeviceSynchronize());
     FS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(fs::g_timeline), (size_t)nwords * sizeof(unsigned long long)));
+    return FS_OK;
+}
+#endif
+
+#ifdef FS_PROBE
+int fs_probe_divide_fast(float den, unsigned long long out_host[3])   // probe build only: see k_selftest_divide_fast
+{
+    if (!out_host || !(den > 0.0f)) return FS_ERR_INVALID;
+    unsigned long long *d = nullptr;
+    FS_HIP(hipMalloc((void **)&d, 3 * sizeof(*d)));
+    FS_HIP(hipMemset(d, 0, 3 * sizeof(*d)));
+    hipLaunchKernelGGL(k_selftest_divide_fast, dim3(256 * 16), dim3(256), 0, nullptr, den, 1.0f / den, d);
+    hipError_t e = hipMemcpy(out_host, d, 3 * sizeof(*d), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fs::hip_fail(e, "fs_probe_divide_fast");
     return FS_OK;
 }
 #endif
