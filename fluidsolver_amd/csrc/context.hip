@@ -901,6 +901,38 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
 
 long fs_particles_count(fs_ctx *c) { return c ? c->n_particles : 0; }
 
+// The reference's own array layout: [Particle] as Swift and MSL lay it out (Part:18-31, Shaders:419-426): position float2 @0,
+// velocity float2 @8, color float4 @16, life @32, mass @36, age @40, stride 48 (any stride >= 44 is accepted).  The update
+// never reads `color` (constant white, Part:215) and the line vertices take their alpha from `life` (Shaders:472), so it
+// is not carried on the device: set ignores it, get leaves the caller's bytes alone.
+namespace {
+constexpr size_t kAosOff[7] = {0, 4, 8, 12, 32, 36, 40};   // px py vx vy life mass age
+}
+int fs_particles_set_aos(fs_ctx *c, long n, const void *particles, size_t stride)
+{
+    if (!c) { fs::set_error("ctx is NULL"); return FS_ERR_INVALID; }
+    if (n < 0 || (n > 0 && !particles) || stride < 44 || (stride & 3)) { fs::set_error("fs_particles_set_aos: bad arguments (stride %zu)", stride); return ctx_fail(c, FS_ERR_INVALID); }
+    std::vector<float> soa((size_t)n * 7);
+    const char *src = static_cast<const char *>(particles);
+    for (long i = 0; i < n; ++i)
+        for (int f = 0; f < 7; ++f) memcpy(&soa[(size_t)f * n + i], src + (size_t)i * stride + kAosOff[f], sizeof(float));
+    const float *p = soa.data();
+    return fs_particles_set(c, n, p, p + n, p + 2 * n, p + 3 * n, p + 4 * n, p + 5 * n, p + 6 * n);
+}
+int fs_particles_get_aos(fs_ctx *c, long n, void *particles, size_t stride)
+{
+    if (!c) { fs::set_error("ctx is NULL"); return FS_ERR_INVALID; }
+    if (n < 0 || (n > 0 && !particles) || stride < 44 || (stride & 3)) { fs::set_error("fs_particles_get_aos: bad arguments (stride %zu)", stride); return ctx_fail(c, FS_ERR_INVALID); }
+    std::vector<float> soa((size_t)n * 7);
+    float *p = soa.data();
+    int rc = fs_particles_get(c, n, p, p + n, p + 2 * n, p + 3 * n, p + 4 * n, p + 5 * n, p + 6 * n);
+    if (rc) return rc;
+    char *dst = static_cast<char *>(particles);
+    for (long i = 0; i < n; ++i)
+        for (int f = 0; f < 7; ++f) memcpy(dst + (size_t)i * stride + kAosOff[f], &soa[(size_t)f * n + i], sizeof(float));
+    return FS_OK;
+}
+
 // ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on the device.  The reference's array holds the live
 // tracers in age order; `count` appends with removeFirst() at the cap (:196-199) leave the last `cap` of (live + new).
 // Here: count the live slots, drop the dead ones and the oldest that do not fit (order kept), write the new tracers

@@ -497,7 +497,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_jacobi_block(JacobiArgs A)
 // at 16384^2) and the diffuse loops on the 5 x 16 tile (256 x 80 cells, 56 VGPRs: 64 of 80 rows stored at depth 8 instead of
 // 48 of 64; -11 us per frame, -5 % per sweep at 16384^2).  The pressure loop stays on 4 x 16: with the divergence tile the
 // 5-row form spills.
-static JacobiTuning g_tuning = {{14, 8}, {4, 7}, 0, 0, 100};
+// Round 3 (profiles/r03_tune_tile_*.log, r03_ab_tile_frames.log): beyond the Infinity Cache the taller tiles win -- fewer rim rows
+// re-read per stored row outweighs their spills and fewer waves: pressure on 5 x 16 (2816 -> 2597 us per 40 sweeps at 16384^2,
+// 374 -> 341 us on a 16384 x 2048 slab), diffuse on 6 x 16 (5694 -> 5515 us); 2 % of those frames.  While the planes sit in
+// the cache nothing moves (3072^2: 470 vs 471 us per frame).  Hence variant 8 = by size (launch_block), the default.
+static JacobiTuning g_tuning = {{14, 8}, {8, 8}, 0, 0, 100};
 JacobiTuning &default_tuning() { return g_tuning; }
 
 template <int OP, int R, int NW, int MINW>
@@ -549,8 +553,12 @@ static int launch_block(const JacobiTuning &tn, const fs_grid *g, int yb, int ye
     A.stagger = tn.stagger;
     A.stagger_mode = tn.stagger_mode;
     // p in, p out and div of the rows in play, against ~3/4 of the 256 MiB Infinity Cache
-    A.xcd_chunked = OP == OP_PRESSURE && 3.0 * (double)g->pitch * (double)(ye - yb) * sizeof(float) < 192.0 * 1024 * 1024;
-    switch (tn.variant[OP]) {
+    const double rows_bytes = (double)g->pitch * (double)(ye - yb) * sizeof(float);
+    A.xcd_chunked = OP == OP_PRESSURE && 3.0 * rows_bytes < 192.0 * 1024 * 1024;
+    int variant = tn.variant[OP];
+    if (variant == 8)   // by size: in the cache 4 x 16 (pressure) / 5 x 16 (diffuse); beyond it one step taller each
+        variant = OP == OP_PRESSURE ? (3.0 * rows_bytes < 192.0 * 1024 * 1024 ? 4 : 7) : (2.0 * rows_bytes < 192.0 * 1024 * 1024 ? 7 : 6);
+    switch (variant) {
     case 1: return launch_variant<OP, 16, 8, 2>(A, g, nplanes, stream);   // 256 x 128 tile, 512 threads
     case 2: return launch_variant<OP, 8, 16, 4>(A, g, nplanes, stream);   // 256 x 128 tile, 1024 threads
     case 3: return launch_variant<OP, 16, 4, 2>(A, g, nplanes, stream);   // 256 x 64 tile, 256 threads
@@ -659,7 +667,7 @@ int tuning_set(JacobiTuning &t, int key, int v)
         return FS_OK;
     case FS_OPT_TILE_VARIANT:
     case FS_OPT_TILE_VARIANT_DIFFUSE:
-        if (v < 0 || v > 7) return FS_ERR_INVALID;
+        if (v < 0 || v > 8) return FS_ERR_INVALID;   // 8: by size (launch_block)
         if (key == FS_OPT_TILE_VARIANT) t.variant[0] = v;
         t.variant[1] = v;
         return FS_OK;

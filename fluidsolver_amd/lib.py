@@ -110,6 +110,8 @@ SIGNATURES = {
     "fs_stage": (_i, [_p, _i, _i]),
     "fs_particles_set": (_i, [_p, _l] + [_p] * 7),
     "fs_particles_get": (_i, [_p, _l] + [_p] * 7),
+    "fs_particles_set_aos": (_i, [_p, _l, _p, _sz]),
+    "fs_particles_get_aos": (_i, [_p, _l, _p, _sz]),
     "fs_default_particle_params": (_i, [C.POINTER(ParticleParams), _f, _f]),
     "fs_particles_update": (_i, [_p, C.POINTER(ParticleParams)]),
     "fs_particles_count": (_l, [_p]),

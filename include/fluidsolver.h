@@ -289,7 +289,8 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      so the partly filled last round of one launch is filled by the other chain, and the dye diffusion loop
                                      of a single-GPU frame runs beside the velocity chain (third stream); 0 = one chain */
        FS_OPT_SLAB_PROFILE = 11,  /* slabs only: 1 = time every wait of the kernels for halo rows (fs_slab_waits) */
-       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone (default 7: 5 rows per lane x 16 waves) */
+       FS_OPT_TILE_VARIANT_DIFFUSE = 10, /* tile shape of the diffuse loops alone (default 8 = by size: 7, 5 rows per lane x 16 waves, while a
+                                     plane's two sides fit the Infinity Cache, 6 beyond) */
        FS_OPT_SLAB_DEFER = 15,    /* slabs only, same value on every rank: 1 (default) = a frame that speculates on its advection halo
                                      (FS_OPT_SLAB_OVERLAP) returns without waiting for the all-reduced CFL bound; the check -- and, when
                                      the guess was too small, the repair: advection planned again with the true depth, the splats
@@ -307,8 +308,9 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
        FS_OPT_SLAB_OVERLAP = 9,   /* slabs only, same value on every rank: 1 (default) hides the halo traffic
                                      behind the kernels (second stream, split advection, speculated halo
                                      depth); 0 = exchange, wait, compute */
-       FS_OPT_TILE_VARIANT = 3    /* Jacobi tile shape (rows per lane x waves): 0 = 8x8, 1 = 16x8,
-                                     2 = 8x16, 3 = 16x4, 4 = 4x16 (default), 5 = 12x8, 6 = 6x16, 7 = 5x16 */ };
+       FS_OPT_TILE_VARIANT = 3    /* Jacobi tile shape of both loops (rows per lane x waves): 0 = 8x8, 1 = 16x8, 2 = 8x16, 3 = 16x4,
+                                     4 = 4x16, 5 = 12x8, 6 = 6x16, 7 = 5x16; default 8 = by size (pressure: 4 while the loop's three
+                                     planes fit the Infinity Cache, 7 beyond) */ };
 
 /* FluidSolver.init() + setResolution (Solver:240-255, :322-343): allocates the fields
  * of a width x height grid on HIP device `device`, all zero (clearTextures :348-366). */
@@ -362,6 +364,12 @@ int fs_particles_set(fs_ctx *ctx, long n, const float *px, const float *py, cons
                      const float *vy, const float *life, const float *mass, const float *age);
 int fs_particles_get(fs_ctx *ctx, long n, float *px, float *py, float *vx, float *vy,
                      float *life, float *mass, float *age);
+/* The same with the reference's own array-of-structures layout, for a host that holds [Particle] (Part:18-31; MSL twin
+ * Shaders:419-426): position float2 @0, velocity float2 @8, color float4 @16, life @32, mass @36, age @40, `stride` bytes
+ * per tracer (48 in Swift and MSL).  `color` is dead state on this path -- constant white (Part:215), never read by
+ * update(), the line's alpha is `life` (Shaders:472) -- so set ignores it and get leaves the caller's bytes untouched. */
+int fs_particles_set_aos(fs_ctx *ctx, long n, const void *particles, size_t stride);
+int fs_particles_get_aos(fs_ctx *ctx, long n, void *particles, size_t stride);
 int fs_default_particle_params(fs_particle_params *pp, float windowW, float windowH);
 int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
 long fs_particles_count(fs_ctx *ctx);

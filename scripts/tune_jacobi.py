@@ -22,7 +22,7 @@ ms = C.c_float()
 res = []
 VARS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else range(8)
 for var in VARS:
-    for depth in (5, 7, 8, 10, 12, 14, 16, 20):
+    for depth in ([int(d) for d in os.environ["FS_DEPTHS"].split(',')] if os.environ.get("FS_DEPTHS") else (5, 7, 8, 10, 12, 14, 16, 20)):
         if th[var] - 2 * depth < 8:
             continue
         L.check((lib.fs_config_set(L.OPT_TILE_VARIANT, var), lib.fs_set_option(s.ctx, L.OPT_TILE_VARIANT, var))[1]); L.check((lib.fs_config_set(L.OPT_BLOCK_DEPTH, depth), lib.fs_set_option(s.ctx, L.OPT_BLOCK_DEPTH, depth))[1])

@@ -861,6 +861,49 @@ def test_tracer_sort_is_invisible(in_graph):
 
 
 @pytest.mark.gpu
+def test_particles_in_the_reference_layout():
+    # fs_particles_set_aos / _get_aos: [Particle] as Swift and MSL lay it out (48-byte stride, ParticleSystem.swift:18-31)
+    # against the seven planar arrays: same tracers after an update; `color` bytes of the caller's buffer are left alone
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    W, H, n = 256, 200, 5000
+    rng = np.random.default_rng(5)
+    arrs = [rng.uniform(0, W, n).astype(F), rng.uniform(0, H, n).astype(F), rng.uniform(-3, 3, n).astype(F), rng.uniform(-3, 3, n).astype(F),
+            rng.uniform(0.3, 1.0, n).astype(F), rng.uniform(0.1, 1.0, n).astype(F), rng.uniform(0, 0.5, n).astype(F)]
+    aos = np.zeros((n, 12), F)
+    for col, a in zip((0, 1, 2, 3, 8, 9, 10), arrs):
+        aos[:, col] = a
+    aos[:, 4:8] = (1.0, 1.0, 1.0, 0.75)   # color
+    aos[:, 11] = 123.0                    # padding
+    out = []
+    for layout in ("soa", "aos"):
+        s = FluidSolver(W, H, max_particles=n)
+        (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = (1.5e-4, 0.0, 0.5, 10.0, 0.002, 6)
+        s.displayMode = None
+        ps = ParticleSystem(s)
+        try:
+            if layout == "soa":
+                ps.set_arrays(*arrs)
+            else:
+                L.check(s._lib.fs_particles_set_aos(s.ctx, n, aos.ctypes.data_as(C.c_void_p), 48), s.ctx)
+            s.applyForce((128.0, 100.0), (40.0, 25.0), (10.0, 20.0, 30.0))
+            s.update()
+            ps.update(s, (W, H))
+            if layout == "soa":
+                out.append(ps.get_arrays())
+            else:
+                back = np.full((n, 12), 7.0, F)
+                L.check(s._lib.fs_particles_get_aos(s.ctx, n, back.ctypes.data_as(C.c_void_p), 48), s.ctx)
+                assert (back[:, 4:8] == 7.0).all() and (back[:, 11] == 7.0).all()
+                out.append([back[:, col].copy() for col in (0, 1, 2, 3, 8, 9, 10)])
+                assert s._lib.fs_particles_set_aos(s.ctx, n, aos.ctypes.data_as(C.c_void_p), 40) == -1
+        finally:
+            s.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(out[0][0], arrs[0])
+
+
+@pytest.mark.gpu
 def test_jacobi_tuning_is_per_context():
     # two contexts in one process: fs_set_option on one (block depth, tile shape) leaves the other's launches alone
     # (they used to share process-wide statics), and both still produce the same bits
@@ -876,7 +919,7 @@ def test_jacobi_tuning_is_per_context():
             s.displayMode = None
         a.set_option(L.OPT_BLOCK_DEPTH, 3)
         a.set_option(L.OPT_TILE_VARIANT, 0)
-        assert lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE) == 14 and lib.fs_config_get(L.OPT_TILE_VARIANT) == 4
+        assert lib.fs_config_get(L.OPT_BLOCK_DEPTH_PRESSURE) == 14 and lib.fs_config_get(L.OPT_TILE_VARIANT) == 8
         import ctypes as C
         from oracle_binding import full_grid   # noqa: F401  (plan dump needs no GPU; the launch counts show the depth in use)
         for f in range(3):
