@@ -450,6 +450,12 @@ def main():
             f0 += 12
         overlap = min(ab, key=ab.get)
         s.set_overlap(overlap)
+        # untimed settle-in: the exchange-free runs of launches of a slab's frame are recorded as hipGraphs once the options have
+        # stayed put for two frames, one recording per combination of buffer roles (up to twelve): all done before the clock starts
+        phase("settle-in frames (segment graphs are recorded)")
+        for f in range(f0, f0 + 16):
+            step(f)
+        f0 += 16
 
     f0 = f0 if slabs else 0
     phase("warm-up + timed frames")
@@ -460,6 +466,7 @@ def main():
     sync_all()
     if slabs:
         s.host_times()     # reset the library's host-time accumulators
+        s.host_breakdown()
     t0 = time.perf_counter()
     for f in range(f0 + args.warmup, f0 + args.warmup + args.steps):
         step(f)
@@ -595,14 +602,16 @@ def main():
                    "note": "us per frame the kernels waited at joins (max over ranks, HIP events, 10 extra frames)"}
         te = torch.tensor([t_enq, host_t["step_us"] - host_t["wait_cfl_us"], host_t["wait_cfl_us"]], dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        out["slab"] = {"exposed_wait_us_per_frame": exposed, "check": slab_check,
+        out["slab"] = {"exposed_wait_us_per_frame": exposed, "check": slab_check, "segment_graphs": s.graph_stats,
+                       "host_breakdown_us_per_frame": {k: v / float(args.steps + pf) for k, v in s.host_breakdown().items()},
                        "host_calls_us_per_frame": float(te[0]) * 1e6 / args.steps,
                        "host_enqueue_us_per_frame": float(te[1]), "host_wait_cfl_us_per_frame": float(te[2]),
                        "host_enqueue_note": "max over ranks, timed frames.  host_calls = wall time of the fs_add_force + fs_step calls before any "
                                             "synchronisation of the caller; inside fs_step (fs_slab_host_times) host_wait_cfl = blocked on the CFL "
-                                            "value that sizes the advection halo (one device round trip + all-reduce per frame: the host runs in "
-                                            "step with the GPU there), host_enqueue = the rest: planning and enqueueing ~25 launches and the "
-                                            "exchanges.  The frame is host-bound when host_enqueue approaches ms_per_step", "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
+                                            "value of the PREVIOUS frame, looked at only after this frame's stencil chain has been enqueued (the "
+                                            "host runs one frame ahead of the GPU, so this wait is where it idles, not where the GPU does), "
+                                            "host_enqueue = the rest: planning, one segment replay, ~8 eager launches and the exchanges.  The frame "
+                                            "is host-bound when host_enqueue approaches ms_per_step", "rows_per_gpu": s.r1 - s.r0, "ghost_rows": s.G, "last_advect_halo": s.last_halo,
                        "exchange_rounds_per_frame": st["exchanges"] / float(max(1, st["frames"])),
                        "halo_rows_sent_per_frame": st["rows_sent"] / float(max(1, st["frames"])),
                        "overlap": bool(overlap), "advection_replans": st["redo"],
