@@ -39,6 +39,17 @@ int project_n_bands(const JacobiTuning &t, const fs_grid *g, int split, float *u
                     float *qa, float *qb, int n, int *result_in_b, void *stream_a, void *stream_b, void *ev_fork, void *ev_join,
                     void *ev_first_a, void *ev_first_b, float *cfl_dev, int cfl_reset);
 
+// argument block + launch geometry of a k_add_forces graph node (passes.hip); must stay put while the node params are in use
+struct SplatNode {
+    GK g;
+    int box[4];
+    float *u, *v, *r, *gch, *b;
+    float f[9];
+    void *args[19];
+    hipKernelNodeParams np;
+};
+void splat_node_params(SplatNode &sn, const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, const float s[9]);
+
 void set_error(const char *fmt, ...);
 const char *get_error();
 int check_grid(const fs_grid *g);

@@ -66,6 +66,9 @@ static void drop_graphs(fs_ctx *c)
     c->stable_frames = 0;
     fs::drop_segment_graphs(c);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto &kv : c->graphs_src) (void)hipGraphDestroy(kv.second);
+    c->graphs_src.clear();
+    c->graphs_splat_nodes.clear();
     c->graphs.clear();
     c->graphs_after.clear();
     c->graphs_epoch.clear();
@@ -355,6 +358,27 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
     return FS_OK;
 }
 
+static int launch_splat(fs_ctx *c, const fs_ctx::Splat &sp)
+{
+    const fs_grid g = fs::grid_of(c, c->G);
+    float *u = c->f[F_VEL].p(), *v = u + c->plane;
+    float *d = c->f[F_DYE].p();
+    return fs_k_addForces(&g, u, v, d, d + c->plane, d + 2 * c->plane, sp.px, sp.py, sp.fx, sp.fy, sp.r, sp.g, sp.b, sp.radius, sp.dt,
+                          c->stream);
+}
+// the splats that were waiting to become nodes of the next frame's graph, launched now, in order
+static int flush_splats(fs_ctx *c)
+{
+    if (c->pending_splats.empty()) return FS_OK;
+    std::vector<fs_ctx::Splat> todo;
+    todo.swap(c->pending_splats);
+    for (const fs_ctx::Splat &sp : todo) {
+        const int rc = launch_splat(c, sp);
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
 extern "C" {
 
 int fs_pitch_for_width(int width) { return width < 1 ? 0 : (width + 63) & ~63; }
@@ -453,6 +477,7 @@ int fs_reset(fs_ctx *c)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    c->pending_splats.clear();   // (splats not yet launched would be wiped by the clears below anyway)
     const size_t pb = c->plane * sizeof(float);
     for (int i = 0; i < F_COUNT; ++i) {
         for (int k = 0; k < 3; ++k)
@@ -503,6 +528,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     auto set = [](int &field, int v) { const bool changed = field != v; field = v; return changed; };
     bool changed = true;
     switch (option) {
@@ -527,6 +553,7 @@ int fs_set_option(fs_ctx *c, int option, int value)
         break;
     case FS_OPT_SPLIT_PLANES: changed = set(c->split_planes, value ? 1 : 0); break;
     case FS_OPT_SPLIT_ROWS: changed = set(c->split_rows, value ? 1 : 0); break;
+    case FS_OPT_SPLAT_IN_GRAPH: c->defer_splats = value ? 1 : 0; changed = false; break;
     case FS_OPT_TRACER_SORT:
         if (value < 0) { fs::set_error("FS_OPT_TRACER_SORT: negative interval"); return ctx_fail(c, FS_ERR_INVALID); }
         c->sort_every = value;
@@ -558,6 +585,7 @@ int fs_get_option(fs_ctx *c, int option, int *value)
     case FS_OPT_SPLIT_PLANES: *value = c->split_planes; break;
     case FS_OPT_SPLIT_ROWS: *value = c->split_rows; break;
     case FS_OPT_TRACER_SORT: *value = c->sort_every; break;
+    case FS_OPT_SPLAT_IN_GRAPH: *value = c->defer_splats; break;
     default: fs::set_error("unknown option %d", option); return ctx_fail(c, FS_ERR_INVALID);
     }
     return FS_OK;
@@ -571,13 +599,16 @@ int fs_add_force(fs_ctx *c, float pos_x, float pos_y, float force_x, float force
     CTX(c);
     if (!color_rgba) { fs::set_error("color is NULL"); return ctx_fail(c, FS_ERR_INVALID); }
     // a slab whose last frame still owes its halo check: remember the splat, the repair has to repeat it (slab.hip)
-    if (c->chk_pending)
-        c->splat_log.push_back(fs_ctx::Splat{pos_x, pos_y, force_x, force_y, color_rgba[0], color_rgba[1], color_rgba[2], radius, deltaTime});
-    const fs_grid g = fs::grid_of(c, c->G);
-    float *u = c->f[F_VEL].p(), *v = u + c->plane;
-    float *d = c->f[F_DYE].p();
-    TRY(c, fs_k_addForces(&g, u, v, d, d + c->plane, d + 2 * c->plane, pos_x, pos_y, force_x, force_y,
-                          color_rgba[0], color_rgba[1], color_rgba[2], radius, deltaTime, c->stream));
+    const fs_ctx::Splat sp{pos_x, pos_y, force_x, force_y, color_rgba[0], color_rgba[1], color_rgba[2], radius, deltaTime};
+    if (c->chk_pending) c->splat_log.push_back(sp);
+    // one GPU, frames replayed: the splat becomes a node of the next frame's graph (fs_step) instead of a launch of its own
+    if (c->world == 1 && c->defer_splats && c->use_graph && c->stable_frames >= 2 && !c->dry &&
+        (int)c->pending_splats.size() < fs_ctx::kMaxPendingSplats && std::isfinite(pos_x) && std::isfinite(pos_y) && std::isfinite(radius)) {
+        c->pending_splats.push_back(sp);
+        return FS_OK;
+    }
+    TRY(c, flush_splats(c));
+    TRY(c, launch_splat(c, sp));
     return FS_OK;
 }
 
@@ -611,17 +642,35 @@ int fs_step(fs_ctx *c)
     // that drags a slider changes them every frame: frames run eagerly (as fast as a replay on large grids, 40 us of
     // host time) until the parameters have stayed put for two frames, and only then is a graph recorded again.
     if (!c->use_graph || c->stable_frames < 2) {
+        TRY(c, flush_splats(c));
         TRY(c, fs::run_frame(c));
         c->stable_frames += 1;
         return FS_OK;
     }
     // (from here on a change of values costs one host-side recording per ping-pong state and no instantiation)
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph
-    // is keyed by the ping-pong state it was recorded from.
+    // is keyed by the ping-pong state it was recorded from -- and by the number of splats that lead it.
+    const size_t k = c->pending_splats.size();
     const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3) |
+                                   ((unsigned long long)k << 56) |
                                    ((unsigned long long)(c->with_particles ? c->part_flip : 0) << 62);   // (which of the two sets of tracer arrays)
+    // argument blocks of the k splat nodes for THIS frame (Solver:444-470: position, force, colour, radius, dt; the fields'
+    // current sides)
+    c->splat_scratch.resize(k);
+    {
+        const fs_grid g = fs::grid_of(c, c->G);
+        float *u = c->f[F_VEL].p(), *v = u + c->plane, *d = c->f[F_DYE].p();
+        for (size_t i = 0; i < k; ++i) {
+            const fs_ctx::Splat &sp = c->pending_splats[i];
+            const float f[9] = {sp.px, sp.py, sp.fx, sp.fy, sp.r, sp.g, sp.b, sp.radius, sp.dt};
+            fs::splat_node_params(c->splat_scratch[i], &g, u, v, d, d + c->plane, d + 2 * c->plane, f);
+        }
+    }
     auto it = c->graphs.find(key);
     if (it != c->graphs.end() && c->graphs_epoch[key] == c->param_epoch) {
+        const std::vector<hipGraphNode_t> &nodes = c->graphs_splat_nodes[key];
+        for (size_t i = 0; i < k; ++i) TRYHIP(c, hipGraphExecKernelNodeSetParams(it->second, nodes[i], &c->splat_scratch[i].np));
+        c->pending_splats.clear();
         TRYHIP(c, hipGraphLaunch(it->second, c->stream));
         set_pingpong(c, c->graphs_after[key]);
         c->stat_frames += 1;
@@ -633,22 +682,37 @@ int fs_step(fs_ctx *c)
     TRYHIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
     int rc = fs::run_frame(c);
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    std::vector<hipGraphNode_t> splat_nodes(k);
+    if (!rc && e == hipSuccess && k > 0) {
+        // the splats in front of everything the frame recorded: a chain of k kernel nodes, every root of the frame behind it
+        size_t nroots = 0;
+        e = hipGraphGetRootNodes(graph, nullptr, &nroots);
+        std::vector<hipGraphNode_t> roots(nroots);
+        if (e == hipSuccess && nroots) e = hipGraphGetRootNodes(graph, roots.data(), &nroots);
+        for (size_t i = 0; i < k && e == hipSuccess; ++i)
+            e = hipGraphAddKernelNode(&splat_nodes[i], graph, i ? &splat_nodes[i - 1] : nullptr, i ? 1 : 0, &c->splat_scratch[i].np);
+        for (size_t r = 0; r < nroots && e == hipSuccess; ++r) e = hipGraphAddDependencies(graph, &splat_nodes[k - 1], &roots[r], 1);
+    }
     if (rc || e != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
         set_pingpong(c, before);
         if (rc) return ctx_fail(c, rc);
-        return ctx_fail(c, fs::hip_fail(e, "hipStreamEndCapture"));
+        return ctx_fail(c, fs::hip_fail(e, "recording the frame's graph"));
     }
     hipGraphExec_t exec = it != c->graphs.end() ? it->second : nullptr;
+    bool keep_graph = false;
     if (exec) {
         hipGraphNode_t bad = nullptr;
         hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
         if (hipGraphExecUpdate(exec, graph, &bad, &res) == hipSuccess && res == hipGraphExecUpdateSuccess)
-            c->stat_graph_updates += 1;
+            c->stat_graph_updates += 1;   // (the exec still answers to the nodes of the graph it was instantiated from)
         else {   // the plan changed after all (or the runtime cannot update this node): instantiate afresh
             (void)hipGetLastError();
             (void)hipGraphExecDestroy(exec);
             c->graphs.erase(key);
+            auto src = c->graphs_src.find(key);
+            if (src != c->graphs_src.end()) { (void)hipGraphDestroy(src->second); c->graphs_src.erase(src); }
             exec = nullptr;
         }
     }
@@ -660,12 +724,16 @@ int fs_step(fs_ctx *c)
             return ctx_fail(c, fs::hip_fail(e, "hipGraphInstantiate"));
         }
         c->stat_graph_instantiations += 1;
+        c->graphs_src[key] = graph;
+        c->graphs_splat_nodes[key] = splat_nodes;
+        keep_graph = true;
     }
-    (void)hipGraphDestroy(graph);
+    if (!keep_graph) (void)hipGraphDestroy(graph);
     // remember where the roles end up so replays can update them without re-recording
     c->graphs[key] = exec;
     c->graphs_after[key] = pingpong_key(c);
     c->graphs_epoch[key] = c->param_epoch;
+    c->pending_splats.clear();
     TRYHIP(c, hipGraphLaunch(exec, c->stream));
     return FS_OK;
 }
@@ -683,6 +751,7 @@ int fs_sync(fs_ctx *c)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     if (c->xstream) TRYHIP(c, hipStreamSynchronize(c->xstream));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     int flag = 0;
@@ -743,6 +812,7 @@ int fs_read_field(fs_ctx *c, int field, float *host, size_t bytes)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     return copy_field(c, field, host, bytes, true, "fs_read_field");
 }
 
@@ -750,6 +820,7 @@ int fs_write_field(fs_ctx *c, int field, const float *host, size_t bytes)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     return copy_field(c, field, const_cast<float *>(host), bytes, false, "fs_write_field");
 }
 
@@ -757,6 +828,7 @@ int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pi
 {
     if (!c || !dev_ptr) return FS_ERR_INVALID;
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     const int np = nplanes_of(field);
     if (plane < 0 || plane >= np) { fs::set_error("bad field/plane %d/%d", field, plane); return ctx_fail(c, FS_ERR_INVALID); }
     if (field == FS_FIELD_PRESSURE) TRY(c, settle_pressure(c));
@@ -765,11 +837,16 @@ int fs_field_device_ptr(fs_ctx *c, int field, int plane, void **dev_ptr, int *pi
     return FS_OK;
 }
 
-void *fs_stream(fs_ctx *c) { return c ? (void *)c->stream : nullptr; }
+void *fs_stream(fs_ctx *c)
+{
+    if (c && !c->pending_splats.empty()) { (void)hipSetDevice(c->device); (void)flush_splats(c); }   // the caller is about to order its own work behind ours
+    return c ? (void *)c->stream : nullptr;
+}
 
 int fs_timer_begin(fs_ctx *c)
 {
     CTX(c);
+    TRY(c, flush_splats(c));
     if (!c->ev0) { TRYHIP(c, hipEventCreate(&c->ev0)); TRYHIP(c, hipEventCreate(&c->ev1)); }
     TRYHIP(c, hipEventRecord(c->ev0, c->stream));
     return FS_OK;
@@ -779,6 +856,7 @@ int fs_timer_end(fs_ctx *c, float *ms)
 {
     CTX(c);
     if (!c->ev0 || !ms) { fs::set_error("fs_timer_end without fs_timer_begin"); return ctx_fail(c, FS_ERR_STATE); }
+    TRY(c, flush_splats(c));
     TRYHIP(c, hipEventRecord(c->ev1, c->stream));
     TRYHIP(c, hipEventSynchronize(c->ev1));
     TRYHIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -789,6 +867,7 @@ int fs_stage(fs_ctx *c, int stage, int n)
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, flush_splats(c));
     SINGLE(c, "fs_stage");
     if (n < 0) { fs::set_error("negative sweep count"); return ctx_fail(c, FS_ERR_INVALID); }
     TRY(c, settle_pressure(c));
@@ -1031,6 +1110,7 @@ int fs_particles_update(fs_ctx *c, const fs_particle_params *pp)
         if (memcmp(&c->pparams, pp, sizeof(*pp)) != 0) { c->pparams = *pp; if (c->with_particles) drop_graphs(c); }
     }
     if (c->n_particles == 0) return FS_OK;   // Part:243 guard
+    TRY(c, flush_splats(c));   // (the lookup reads the velocity the splats write)
     TRY(c, tracer_maybe_sort(c));
     TRY(c, st_particles(c));
     return FS_OK;

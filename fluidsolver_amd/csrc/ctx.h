@@ -150,6 +150,16 @@ struct fs_ctx {
     std::unordered_map<unsigned long long, hipGraphExec_t> graphs;
     std::unordered_map<unsigned long long, unsigned long long> graphs_after;  // ping-pong state a replay leaves
     std::unordered_map<unsigned long long, unsigned long long> graphs_epoch;  // param_epoch the graph's kernel arguments are from
+    struct Splat { float px, py, fx, fy, r, g, b, radius, dt; };
+    // Splats of a single-GPU context whose frames are replayed are not launched by fs_add_force: they wait here (at most
+    // kMaxPendingSplats) and become the first nodes of the next fs_step's graph, their arguments set per replay; any other
+    // call that looks at or enqueues on the fields launches them first (flush_splats).
+    static constexpr int kMaxPendingSplats = 8;
+    int defer_splats = 0;               // FS_OPT_SPLAT_IN_GRAPH (off: measured slower on this runtime, profiles/r03_o_splat_in_graph.log)
+    std::vector<Splat> pending_splats;
+    std::unordered_map<unsigned long long, hipGraph_t> graphs_src;                    // the graph an exec was instantiated from (owns the splat nodes)
+    std::unordered_map<unsigned long long, std::vector<hipGraphNode_t>> graphs_splat_nodes;
+    std::vector<fs::SplatNode> splat_scratch;
     unsigned long long param_epoch = 0; // bumped when a scalar baked into the kernel nodes changes (fs_set_params)
     long stat_graph_updates = 0, stat_graph_instantiations = 0;
     // Slab frames (world > 1): the exchange-free runs of kernel launches of a plan ("segments") are recorded as hipGraphs
@@ -167,7 +177,6 @@ struct fs_ctx {
     bool chk_pending = false;
     int chk_h = 0, chk_slot = 0;
     fs::Field chk_saved[fs::F_COUNT];
-    struct Splat { float px, py, fx, fy, r, g, b, radius, dt; };
     std::vector<Splat> splat_log;
     // statistics of the slab path
     long stat_exchanges = 0, stat_rows = 0, stat_frames = 0, stat_redo = 0;

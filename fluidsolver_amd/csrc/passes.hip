@@ -1186,6 +1186,19 @@ int fs_k_advect_both(const fs_grid *g, const float *u, const float *v, float *u_
     return FS_OK;
 }
 
+// bounding box of the cells with dist < radius, clipped to the rows the launch may touch; false: no such cell
+static bool splat_box(const fs_grid *g, float pos_x, float pos_y, float radius, int box[4])
+{
+    if (!(radius > 0.0f) || g->ye <= g->yb) return false;  // dist < radius can never hold
+    // every cell with dist < radius lies in [pos-radius, pos+radius]
+    double lo_x = floor((double)pos_x - radius), hi_x = ceil((double)pos_x + radius);
+    double lo_y = floor((double)pos_y - radius), hi_y = ceil((double)pos_y + radius);
+    if (hi_x < 0 || hi_y < g->yb || lo_x > g->width - 1 || lo_y > g->ye - 1) return false;
+    box[0] = (int)fmax(lo_x, 0.0); box[2] = (int)fmin(hi_x, (double)g->width - 1);
+    box[1] = (int)fmax(lo_y, (double)g->yb); box[3] = (int)fmin(hi_y, (double)g->ye - 1);
+    return box[2] >= box[0] && box[3] >= box[1];
+}
+
 int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, float pos_x, float pos_y,
                    float force_x, float force_y, float color_r, float color_g, float color_b, float radius,
                    float deltaTime, void *stream)
@@ -1194,20 +1207,46 @@ int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, f
     REQUIRE(u && v && r && gch && b, "null pointer");
     REQUIRE(isfinite(pos_x) && isfinite(pos_y) && isfinite(radius), "non-finite splat geometry");
     EMPTY_OK(g);
-    if (!(radius > 0.0f)) return FS_OK;  // dist < radius can never hold
-    // every cell with dist < radius lies in [pos-radius, pos+radius]
-    double lo_x = floor((double)pos_x - radius), hi_x = ceil((double)pos_x + radius);
-    double lo_y = floor((double)pos_y - radius), hi_y = ceil((double)pos_y + radius);
-    if (hi_x < 0 || hi_y < g->yb || lo_x > g->width - 1 || lo_y > g->ye - 1) return FS_OK;
-    int bx0 = (int)fmax(lo_x, 0.0), bx1 = (int)fmin(hi_x, (double)g->width - 1);
-    int by0 = (int)fmax(lo_y, (double)g->yb), by1 = (int)fmin(hi_y, (double)g->ye - 1);
-    if (bx1 < bx0 || by1 < by0) return FS_OK;
-    dim3 grid((bx1 - bx0 + 64) / 64, (by1 - by0 + 4) / 4, 1);
-    hipLaunchKernelGGL(k_add_forces, grid, kBlock, 0, STREAM, make_gk(g), bx0, by0, bx1, by1, u, v, r, gch, b, pos_x,
+    int box[4];
+    if (!splat_box(g, pos_x, pos_y, radius, box)) return FS_OK;
+    dim3 grid((box[2] - box[0] + 64) / 64, (box[3] - box[1] + 4) / 4, 1);
+    hipLaunchKernelGGL(k_add_forces, grid, kBlock, 0, STREAM, make_gk(g), box[0], box[1], box[2], box[3], u, v, r, gch, b, pos_x,
                        pos_y, force_x, force_y, color_r, color_g, color_b, radius, deltaTime);
     FS_LAUNCH_CHECK("k_add_forces");
     return FS_OK;
 }
+
+}  // extern "C"
+
+// The splat as a NODE of a frame's graph (context.hip): its argument block and launch geometry, set afresh before every
+// replay.  A splat that touches no cell keeps its node as one workgroup over an empty box.
+namespace fs {
+void splat_node_params(SplatNode &sn, const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, const float s[9])
+{
+    sn.g = make_gk(g);
+    sn.u = u; sn.v = v; sn.r = r; sn.gch = gch; sn.b = b;
+    for (int i = 0; i < 9; ++i) sn.f[i] = s[i];   // px py fx fy cr cg cb radius dt
+    unsigned gx = 1, gy = 1;
+    if (isfinite(s[0]) && isfinite(s[1]) && isfinite(s[7]) && splat_box(g, s[0], s[1], s[7], sn.box)) {
+        gx = (unsigned)(sn.box[2] - sn.box[0] + 64) / 64;
+        gy = (unsigned)(sn.box[3] - sn.box[1] + 4) / 4;
+    } else {
+        sn.box[0] = sn.box[1] = 0; sn.box[2] = sn.box[3] = -1;   // every thread leaves at once
+    }
+    void *args[19] = {&sn.g, &sn.box[0], &sn.box[1], &sn.box[2], &sn.box[3], &sn.u, &sn.v, &sn.r, &sn.gch, &sn.b,
+                      &sn.f[0], &sn.f[1], &sn.f[2], &sn.f[3], &sn.f[4], &sn.f[5], &sn.f[6], &sn.f[7], &sn.f[8]};
+    for (int i = 0; i < 19; ++i) sn.args[i] = args[i];
+    sn.np = hipKernelNodeParams{};
+    sn.np.func = reinterpret_cast<void *>(&k_add_forces);
+    sn.np.gridDim = dim3(gx, gy, 1);
+    sn.np.blockDim = kBlock;
+    sn.np.sharedMemBytes = 0;
+    sn.np.kernelParams = sn.args;
+    sn.np.extra = nullptr;
+}
+}  // namespace fs
+
+extern "C" {
 
 int fs_k_particles_update(const fs_grid *g, const float *u, const float *v, const fs_particle_params *pp, long n,
                           float *px, float *py, float *vx, float *vy, float *life, const float *mass, float *age,

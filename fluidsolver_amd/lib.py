@@ -22,7 +22,7 @@ DISPLAY_NONE, DISPLAY_DENSITY, DISPLAY_VELOCITY, DISPLAY_SPEED, DISPLAY_VORTICIT
 OPT_USE_GRAPH, OPT_BLOCK_DEPTH, OPT_WITH_PARTICLES, OPT_TILE_VARIANT, OPT_FUSE = 0, 1, 2, 3, 4
 OPT_BLOCK_DEPTH_PRESSURE, OPT_BLOCK_DEPTH_DIFFUSE, OPT_STAGGER, OPT_STAGGER_MODE, OPT_SLAB_OVERLAP = 5, 6, 7, 8, 9
 OPT_TILE_VARIANT_DIFFUSE, OPT_SLAB_PROFILE, OPT_SPLIT_PLANES, OPT_SPLIT_ROWS, OPT_BAND_DELAY = 10, 11, 12, 13, 14
-OPT_SLAB_DEFER, OPT_SEGMENT_GRAPH_AFTER, OPT_SLAB_SERIALIZE, OPT_TRACER_SORT = 15, 16, 17, 18
+OPT_SLAB_DEFER, OPT_SEGMENT_GRAPH_AFTER, OPT_SLAB_SERIALIZE, OPT_TRACER_SORT, OPT_SPLAT_IN_GRAPH = 15, 16, 17, 18, 19
 (STAGE_VORTICITY, STAGE_APPLY_VORTICITY, STAGE_DIFFUSE_VELOCITY, STAGE_DIVERGENCE, STAGE_CLEAR_PRESSURE,
  STAGE_PRESSURE, STAGE_SUBTRACT_GRADIENT, STAGE_ADVECT_VELOCITY, STAGE_DIFFUSE_DENSITY, STAGE_ADVECT_DENSITY,
  STAGE_FADE, STAGE_RENDER, STAGE_PRESSURE_CLEARED, STAGE_PROJECT) = range(14)

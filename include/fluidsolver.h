@@ -297,6 +297,12 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      applied since repeated -- runs at the start of the next call on the context that is not
                                      fs_add_force (fs_step, fs_sync, a read, fs_slab_info ...), where FS_ERR_HALO is then reported.
                                      0 = fs_step waits for the bound itself (one device round trip per frame) */
+       FS_OPT_SPLAT_IN_GRAPH = 19, /* one GPU: 1 = while frames are replayed, fs_add_force does not launch: up to 8 splats wait and
+                                     become the first nodes of the next fs_step's graph, their arguments set per replay; any other call
+                                     that reads or orders work behind the fields (fs_sync, reads, writes, fs_stage, fs_stream,
+                                     fs_timer_*, fs_particles_update) launches them first, so the order of effects is the call order.
+                                     Default 0: on ROCm 7.2 a node in front of the frame's graph costs more than the launch it
+                                     replaces (459 -> 475 us per frame at 3072^2, profiles/r03_o_splat_in_graph.log) */
        FS_OPT_TRACER_SORT = 18,   /* one GPU: frames between two re-orderings of the tracer arrays by the cache line their velocity lookup
                                      reads (default 32; 0 = never).  Invisible outside: every call that exposes slot order restores it */
        FS_OPT_SLAB_SERIALIZE = 17, /* local groups only, a measurement aid (set it on EVERY slab of the group): 1 = the K slabs, which share

@@ -278,6 +278,48 @@ def test_update_boundary_invariants():
             assert not s.read_field(f)[0][sl].any()
 
 
+@pytest.mark.parametrize("in_graph", [1, 0])
+def test_splats_as_graph_nodes_match_oracle(oracle, in_graph):
+    """FS_OPT_SPLAT_IN_GRAPH: while frames are replayed fs_add_force only queues the splat; fs_step makes the queued splats
+    the first nodes of the frame's graph and sets their arguments per replay.  A varying number of splats per frame (0 to
+    10: more than the 8 a graph takes), some off the grid, some of radius 0, a read and a timer mark between splat and step
+    (which must launch what is queued first): the oracle's bits, and the graphs are really replayed."""
+    from fluidsolver_amd import lib as L
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, Params
+    W, H, params = 520, 300, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 9)
+    s = make_solver(W, H, params)
+    s.set_option(L.OPT_SPLAT_IN_GRAPH, in_graph)
+    o = oracle.solver(W, H)
+    p = Params(*params)
+    counts = [1, 1, 1, 2, 2, 0, 3, 3, 1, 10, 2, 2, 1, 1, 3, 3, 0, 0, 2, 2, 1, 1]
+    try:
+        for f, k in enumerate(counts):
+            for j in range(k):
+                pos = (40.0 + 37.0 * ((f + 3 * j) % 13), 20.0 + 23.0 * ((2 * f + j) % 12))
+                if (f + j) % 7 == 3:
+                    pos = (-40.0, 5000.0)                       # off the grid: touches nothing
+                radius = 0.0 if (f + j) % 11 == 5 else 4.0 + j  # radius 0: dist < radius never holds
+                force, col = (20.0 - 3 * j, -7.0 + f), (10.0 * j, 5.0, 30.0 - f)
+                s.forceRadius = radius
+                s.applyForce(pos, force, col)
+                o.add_force(pos, force, col, radius, p.deltaTime)
+            if f == 8:     # a read between splat and step
+                assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY))
+            if f == 12:    # a timer mark between splat and step: the queued splats are launched in front of it
+                L.check(L.load().fs_timer_begin(s.ctx), s.ctx)
+            s.update()
+            o.update(p)
+        s.sync()
+        assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY))
+        assert np.array_equal(s.read_field(L.FIELD_PRESSURE), o.field(PRESSURE))
+        assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY))
+        st = (C.c_long * 3)()
+        L.check(L.load().fs_graph_stats(s.ctx, st))
+        assert st[0] >= 2, list(st)
+    finally:
+        s.close()
+
+
 def test_vorticity_plane_is_refused_when_the_frame_did_not_write_it(oracle):
     """On grids at least 512 wide fs_step computes curl + confinement in one pass and never writes the vorticity plane:
     fs_read_field must say so (FS_ERR_STATE) instead of handing out an old plane; FS_OPT_FUSE 0 keeps the plane, and it
