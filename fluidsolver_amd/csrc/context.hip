@@ -184,8 +184,34 @@ static int ensure_part_t(fs_ctx *c)
             return fs::hip_fail(e, "hipMalloc(tracer partner arrays)");
         }
     }
+    FS_HIP(hipMemsetAsync(c->part_t[4], 0, (size_t)c->max_particles * sizeof(float), c->stream));
     return FS_OK;
 }
+// Invariant of a single-GPU context: in the CURRENT arrays every slot from n_particles up to the capacity has life 0, so
+// the tracer node of a frame's graph can be launched over a rounded-up slot count (tracer_bound) and spawning a few
+// tracers does not change the node.  Whoever fills the partner arrays with m tracers clears the rest of their life plane.
+static int clear_life_tail(fs_ctx *c, float *life, long m)
+{
+    if (!life || m >= c->max_particles) return FS_OK;
+    FS_HIP(hipMemsetAsync(life + m, 0, (size_t)(c->max_particles - m) * sizeof(float), c->stream));
+    return FS_OK;
+}
+static long tracer_bound(const fs_ctx *c)
+{
+    if (c->world > 1) return c->n_particles;
+    return std::min(c->max_particles, (c->n_particles + 16383L) & ~16383L);
+}
+static int ensure_spawn_sums(fs_ctx *c)
+{
+    const long nb = fs::tracer_blocks(c->max_particles);
+    if (c->spawn_sums_cap >= nb + 1) return FS_OK;
+    (void)hipFree(c->spawn_sums);
+    c->spawn_sums = nullptr; c->spawn_sums_cap = 0;   // (a failed allocation below leaves "none", not a stale size)
+    FS_HIP(hipMalloc((void **)&c->spawn_sums, (size_t)(nb + 1) * sizeof(int)));
+    c->spawn_sums_cap = nb + 1;
+    return FS_OK;
+}
+
 // back to slot order: every call that shows the arrays to the host, or relies on their age order, comes through here
 static int tracer_restore_order(fs_ctx *c)
 {
@@ -194,10 +220,33 @@ static int tracer_restore_order(fs_ctx *c)
     c->frames_since_sort = 1 << 20;   // sorted again by the next update
     if (c->n_particles > 0) {
         int rc = fs::tracer_unsort(c->n_particles, c->part, c->part_t, c->part_perm, c->stream);
+        if (!rc) rc = clear_life_tail(c, c->part_t[4], c->n_particles);
         if (rc) return rc;
         for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
         c->part_flip ^= 1;
     }
+    return FS_OK;
+}
+// The compaction a fast-path spawn put off: drop the slots it marked removed (slot order first).  Blocking: the count
+// comes back to the host.  Allocates nothing (the fast path made sure the partner arrays and the scan buffer exist).
+static int tracer_settle_removed(fs_ctx *c)
+{
+    if (!c->removed_pending) return FS_OK;
+    int rc = tracer_restore_order(c);
+    if (rc) return rc;
+    c->removed_pending = false;
+    const long n = c->n_particles;
+    if (n == 0) return FS_OK;
+    rc = fs::tracer_count_live(n, c->part[4], c->spawn_sums, true, c->stream);
+    if (rc) return rc;
+    int total = 0;
+    FS_HIP(hipMemcpyAsync(&total, c->spawn_sums + fs::tracer_blocks(n), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = fs::tracer_compact(n, c->part, c->part_t, c->spawn_sums, 0, true, c->stream))) return rc;
+    if ((rc = clear_life_tail(c, c->part_t[4], total))) return rc;
+    for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+    c->part_flip ^= 1;
+    c->n_particles = total;
     return FS_OK;
 }
 // called once per tracer update, before it is enqueued (never under stream capture: it allocates on first use)
@@ -227,6 +276,7 @@ static int tracer_maybe_sort(fs_ctx *c)
     }
     rc = fs::tracer_sort(&c->grid, &c->pparams, c->n_particles, c->part, c->part_t, c->sort_keys, c->sort_hist,
                          c->part_sorted ? c->part_perm : nullptr, c->part_perm_t, c->stream);
+    if (!rc) rc = clear_life_tail(c, c->part_t[4], c->n_particles);
     if (rc) return rc;
     for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
     std::swap(c->part_perm, c->part_perm_t);
@@ -348,6 +398,10 @@ int create_common(int width, int height, int device, fs_comm *comm, int world, i
     for (int i = 0; i < 7 && !rc && max_particles > 0; ++i) {
         e = hipMalloc((void **)&c->part[i], (size_t)max_particles * sizeof(float));
         if (e != hipSuccess) rc = fs::hip_fail(e, "hipMalloc(particles)");
+    }
+    if (!rc && max_particles > 0) {   // (life 0 = an empty slot, see tracer_bound)
+        e = hipMemsetAsync(c->part[4], 0, (size_t)max_particles * sizeof(float), c->stream);
+        if (e != hipSuccess) rc = fs::hip_fail(e, "hipMemsetAsync(life)");
     }
     // (the staging area only serves fs_particle_lines_static, which reports its absence itself: not a reason to fail a context)
     if (!rc && scratch_for_device(device, &c->lines_scratch)) { c->lines_scratch = nullptr; (void)hipGetLastError(); }
@@ -651,7 +705,7 @@ int fs_step(fs_ctx *c)
     // Buffer roles alternate between frames when a swap count is odd, so a captured graph
     // is keyed by the ping-pong state it was recorded from -- and by the number of splats that lead it.
     const size_t k = c->pending_splats.size();
-    const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? c->n_particles : 0) << 3) |
+    const unsigned long long key = pingpong_key(c) | ((unsigned long long)(c->with_particles ? tracer_bound(c) : 0) << 3) |
                                    ((unsigned long long)k << 56) |
                                    ((unsigned long long)(c->with_particles ? c->part_flip : 0) << 62);   // (which of the two sets of tracer arrays)
     // argument blocks of the k splat nodes for THIS frame (Solver:444-470: position, force, colour, radius, dt; the fields'
@@ -909,6 +963,7 @@ int fs_particles_reserve(fs_ctx *c, long capacity)
     c->n_particles = 0;
     c->max_particles = 0;
     c->part_sorted = false;
+    c->removed_pending = false;
     (void)hipFree(c->part_perm); (void)hipFree(c->part_perm_t); (void)hipFree(c->sort_keys);
     c->part_perm = c->part_perm_t = c->sort_keys = nullptr;
     c->sort_cap = 0;
@@ -928,6 +983,7 @@ int fs_particles_reserve(fs_ctx *c, long capacity)
         TRYHIP(c, hipHostMalloc((void **)&c->tr_matrix_host, w * w * sizeof(int), hipHostMallocDefault));
     }
     c->max_particles = capacity;
+    if (capacity > 0) TRYHIP(c, hipMemsetAsync(c->part[4], 0, (size_t)capacity * sizeof(float), c->stream));   // (life 0 = an empty slot)
     return FS_OK;
 }
 
@@ -953,7 +1009,8 @@ int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const 
     const long mine = hi - lo;
     if (mine > c->max_particles) { fs::set_error("particle count %ld exceeds capacity %ld", mine, c->max_particles); return ctx_fail(c, FS_ERR_INVALID); }
     const float *src[7] = {px, py, vx, vy, life, mass, age};
-    TRY(c, tracer_restore_order(c));   // (tracers beyond the new ones keep their slots)
+    TRY(c, tracer_settle_removed(c));
+    TRY(c, tracer_restore_order(c));
     TRYHIP(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 7 && mine > 0; ++i) {
         if (!src[i]) { fs::set_error("NULL particle array %d", i); return ctx_fail(c, FS_ERR_INVALID); }
@@ -961,6 +1018,7 @@ int fs_particles_set(fs_ctx *c, long n, const float *px, const float *py, const 
     }
     if (mine != c->n_particles) drop_graphs(c);
     c->n_particles = mine;
+    if (c->world == 1) TRY(c, clear_life_tail(c, c->part[4], mine));
     return FS_OK;
 }
 
@@ -969,6 +1027,7 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, tracer_settle_removed(c));
     if (n < 0 || n > c->n_particles) { fs::set_error("asked for %ld of %ld particles", n, c->n_particles); return ctx_fail(c, FS_ERR_INVALID); }
     float *dst[7] = {px, py, vx, vy, life, mass, age};
     TRY(c, tracer_restore_order(c));
@@ -978,7 +1037,13 @@ int fs_particles_get(fs_ctx *c, long n, float *px, float *py, float *vx, float *
     return FS_OK;
 }
 
-long fs_particles_count(fs_ctx *c) { return c ? c->n_particles : 0; }
+// (Blocking when a spawn has put its compaction off: the count is the reference's particleCount, live slots as of the last spawn.)
+long fs_particles_count(fs_ctx *c)
+{
+    if (!c) return 0;
+    if (c->removed_pending && hipSetDevice(c->device) == hipSuccess) (void)tracer_settle_removed(c);
+    return c->n_particles;
+}
 
 // The reference's own array layout: [Particle] as Swift and MSL lay it out (Part:18-31, Shaders:419-426): position float2 @0,
 // velocity float2 @8, color float4 @16, life @32, mass @36, age @40, stride 48 (any stride >= 44 is accepted).  The update
@@ -1014,27 +1079,36 @@ int fs_particles_get_aos(fs_ctx *c, long n, void *particles, size_t stride)
 
 // ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on the device.  The reference's array holds the live
 // tracers in age order; `count` appends with removeFirst() at the cap (:196-199) leave the last `cap` of (live + new).
-// Here: count the live slots, drop the dead ones and the oldest that do not fit (order kept), write the new tracers
-// behind them.  Blocking (the live count comes back to the host, like the reference's particleCount, :229).
+// While there is room for the new tracers behind the slots in use: the slots that are dead now are marked removed, the
+// new tracers are appended, nothing comes back to the host and the frame graphs stay (the compaction is owed to the next
+// call that shows the arrays or the count: tracer_settle_removed).  Otherwise: count the live slots, drop the dead ones and the
+// oldest that do not fit (order kept), write the new tracers behind them -- blocking, the live count comes back to the host.
 int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, unsigned seed)
 {
     CTX(c);
     SINGLE(c, "fs_particles_spawn");
     if (count < 0) { fs::set_error("negative spawn count"); return ctx_fail(c, FS_ERR_INVALID); }
-    const long cap = c->max_particles, n = c->n_particles;
+    const long cap = c->max_particles;
     if (cap == 0) return FS_OK;   // (count == 0 still drops the dead slots: the reference's array never holds any)
     TRY(c, ensure_part_t(c));
-    TRY(c, tracer_restore_order(c));   // the slots are in age order, which decides who is dropped at the cap
-    const long nb = fs::tracer_blocks(cap);
-    if (c->spawn_sums_cap < nb + 1) {
-        (void)hipFree(c->spawn_sums);
-        c->spawn_sums = nullptr; c->spawn_sums_cap = 0;   // (a failed allocation below leaves "none", not a stale size)
-        TRYHIP(c, hipMalloc((void **)&c->spawn_sums, (size_t)(nb + 1) * sizeof(int)));
-        c->spawn_sums_cap = nb + 1;
+    TRY(c, ensure_spawn_sums(c));
+    if (c->n_particles + count <= cap) {
+        const long n = c->n_particles;
+        TRY(c, fs::tracer_mark_removed(n, c->part[4], c->stream));
+        // (sorted arrays: the new tracers go behind them, their slots are their positions)
+        TRY(c, fs::tracer_spawn(n, 0, count, c->part, x, y, radius, seed, c->part_sorted ? c->part_perm : nullptr, c->stream));
+        c->removed_pending = true;
+        const long bound = tracer_bound(c);
+        c->n_particles = n + count;
+        if (c->with_particles && tracer_bound(c) != bound) drop_graphs(c);   // (the tracer node's slot count is rounded up: rarely)
+        return FS_OK;
     }
+    TRY(c, tracer_settle_removed(c));
+    TRY(c, tracer_restore_order(c));   // the slots are in age order, which decides who is dropped at the cap
+    const long n = c->n_particles;
     long live = 0;
     if (n > 0) {
-        TRY(c, fs::tracer_count_live(n, c->part[4], c->spawn_sums, c->stream));
+        TRY(c, fs::tracer_count_live(n, c->part[4], c->spawn_sums, false, c->stream));
         int total = 0;
         TRYHIP(c, hipMemcpyAsync(&total, c->spawn_sums + fs::tracer_blocks(n), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         TRYHIP(c, hipStreamSynchronize(c->stream));
@@ -1043,9 +1117,10 @@ int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, un
     const long after = std::min(cap, live + count);                   // Part:229 particleCount
     const long drop = std::max(0L, live + count - cap);               // oldest tracers pushed out at the cap, :196-199
     const long kept = live - std::min(drop, live);
-    if (n > 0) TRY(c, fs::tracer_compact(n, c->part, c->part_t, c->spawn_sums, drop, c->stream));
+    if (n > 0) TRY(c, fs::tracer_compact(n, c->part, c->part_t, c->spawn_sums, drop, false, c->stream));
     const long j0 = std::max(0L, count - cap);                        // more new tracers than slots: the first ones are pushed out too
-    TRY(c, fs::tracer_spawn(kept, j0, count, c->part_t, x, y, radius, seed, c->stream));
+    TRY(c, fs::tracer_spawn(kept, j0, count, c->part_t, x, y, radius, seed, nullptr, c->stream));
+    TRY(c, clear_life_tail(c, c->part_t[4], after));
     for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
     c->part_flip ^= 1;
     c->n_particles = after;
@@ -1057,6 +1132,7 @@ int fs_particle_lines(fs_ctx *c, float viewportW, float viewportH, float particl
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, tracer_settle_removed(c));
     const long n = c->n_particles;
     if (n == 0) return FS_OK;
     if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }
@@ -1082,6 +1158,7 @@ int fs_particle_lines_static(fs_ctx *c, float viewportW, float viewportH, float 
 {
     CTX(c);
     TRY(c, fs::settle(c));
+    TRY(c, tracer_settle_removed(c));   // (allocates nothing either)
     const long n = c->n_particles;
     if (n == 0) return FS_OK;
     if (!host_xy4 || !host_alpha) { fs::set_error("fs_particle_lines_static: NULL output"); return ctx_fail(c, FS_ERR_INVALID); }

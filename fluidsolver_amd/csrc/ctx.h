@@ -205,6 +205,10 @@ struct fs_ctx {
     int *part_perm = nullptr, *part_perm_t = nullptr, *sort_keys = nullptr, *sort_hist = nullptr;
     long sort_cap = 0, sort_hist_cap = 0;
     long stat_sorts = 0;
+    // fs_particles_spawn while there is room appends without compacting (no host round trip, the frame graphs stay): the
+    // slots that were dead at that moment are marked removed and dropped by the next call that shows the arrays or their
+    // count to the host (tracer_settle_removed).  n_particles counts SLOTS (removed ones included) until then.
+    bool removed_pending = false;
     int *spawn_sums = nullptr;          // fs_particles_spawn: live counts per block of 256 slots, then their scan (blocks + 1 ints)
     long spawn_sums_cap = 0;
     float *lines_scratch = nullptr;     // this device's copy of the static staging array (fs_particle_lines_static); not owned
@@ -224,9 +228,10 @@ int tracer_sort(const fs_grid *g, const fs_particle_params *pp, long n, float *c
 int tracer_unsort(long n, float *const in[7], float *const out[7], const int *perm, hipStream_t st);
 // tracer spawning (passes.hip)
 long tracer_blocks(long n);
-int tracer_count_live(long n, const float *life, int *sums, hipStream_t st);
-int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, hipStream_t st);
-int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, hipStream_t st);
+int tracer_mark_removed(long n, float *life, hipStream_t st);
+int tracer_count_live(long n, const float *life, int *sums, bool removed_only, hipStream_t st);
+int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, bool removed_only, hipStream_t st);
+int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, int *perm, hipStream_t st);
 
 // frame planner (slab.hip)
 void plan_update_a(fs_ctx *c, int h_spec);   // update() up to subtractGradient (+ the CFL reduction on slabs);

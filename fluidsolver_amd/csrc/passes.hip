@@ -724,10 +724,23 @@ __global__ __launch_bounds__(256) void k_tracer_scatter(GK g, fs_particle_params
 // slots until the next spawn, which (1) counts the live tracers per block of 256, (2) scans the counts, (3) copies the
 // live tracers, in order, minus the `drop` oldest, to the partner arrays and (4) writes the new ones behind them.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tracer_live_count(long n, const float *__restrict__ life, int *__restrict__ block_sums)
+// A slot is dead when its life is zero.  fs_particles_spawn's fast path cannot compact (that needs the live count on the
+// host), so it marks the slots that are dead AT THAT MOMENT as removed -- life = -0.0f, still "== 0" to every kernel -- and
+// the compaction that is owed later drops exactly those (removed_only), not the tracers that have died since.
+__device__ __forceinline__ bool tracer_kept(float life, bool removed_only)
+{
+    return removed_only ? __float_as_uint(life) != 0x80000000u : life != 0.0f;
+}
+__global__ __launch_bounds__(256) void k_tracer_mark_removed(long n, float *__restrict__ life)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n && life[i] != 0.0f;
+    if (i < n && life[i] == 0.0f) life[i] = -0.0f;
+}
+__global__ __launch_bounds__(256) void k_tracer_live_count(long n, const float *__restrict__ life, int *__restrict__ block_sums,
+                                                           bool removed_only)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n && tracer_kept(life[i], removed_only);
     const int cnt = __popcll(__ballot(live));
     __shared__ int w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
@@ -752,10 +765,10 @@ __global__ __launch_bounds__(64) void k_tracer_scan(int nb, int *sums)
     if (lane == 63) sums[nb] = incl;
 }
 __global__ __launch_bounds__(256) void k_tracer_compact(long n, TracerArrays in, TracerArrays out, const int *__restrict__ block_off,
-                                                        long drop)
+                                                        long drop, bool removed_only)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n && in.a[4][i] != 0.0f;
+    const bool live = i < n && tracer_kept(in.a[4][i], removed_only);
     const unsigned long long b = __ballot(live);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int w[4];
@@ -777,7 +790,7 @@ __device__ __forceinline__ float spawn_draw(unsigned &x, float lo, float hi)
 }
 // new tracer j (j0 <= j < count) -> slot first + (j - j0); its four draws from an xorshift32 stream of its own
 __global__ __launch_bounds__(256) void k_tracer_spawn(long first, long j0, long count, TracerArrays out, float x, float y,
-                                                      float radius, unsigned seed)
+                                                      float radius, unsigned seed, int *__restrict__ perm)
 {
     const long j = j0 + (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= count) return;
@@ -791,6 +804,7 @@ __global__ __launch_bounds__(256) void k_tracer_spawn(long first, long j0, long 
     out.a[0][s] = x + ox; out.a[1][s] = y + oy;            // Part:218
     out.a[2][s] = 0.0f; out.a[3][s] = 0.0f;                // Part:208
     out.a[4][s] = alpha; out.a[5][s] = ms; out.a[6][s] = 0.0f;   // Part:221-223
+    if (perm) perm[s] = (int)s;   // appended behind sorted arrays: the new tracer's slot is its position
 }
 
 // ---------------------------------------------------------------------------
@@ -950,28 +964,35 @@ int tracer_unsort(long n, float *const in[7], float *const out[7], const int *pe
 
 // spawn helpers for the context (context.hip); sums holds blocks + 1 ints
 long tracer_blocks(long n) { return (n + 255) / 256; }
-int tracer_count_live(long n, const float *life, int *sums, hipStream_t st)
+int tracer_mark_removed(long n, float *life, hipStream_t st)
+{
+    if (n <= 0) return FS_OK;
+    hipLaunchKernelGGL(k_tracer_mark_removed, dim3((unsigned)tracer_blocks(n)), dim3(256), 0, st, n, life);
+    FS_LAUNCH_CHECK("k_tracer_mark_removed");
+    return FS_OK;
+}
+int tracer_count_live(long n, const float *life, int *sums, bool removed_only, hipStream_t st)
 {
     const long nb = tracer_blocks(n);
-    hipLaunchKernelGGL(k_tracer_live_count, dim3((unsigned)nb), dim3(256), 0, st, n, life, sums);
+    hipLaunchKernelGGL(k_tracer_live_count, dim3((unsigned)nb), dim3(256), 0, st, n, life, sums, removed_only);
     hipLaunchKernelGGL(k_tracer_scan, dim3(1), dim3(64), 0, st, (int)nb, sums);
     FS_LAUNCH_CHECK("k_tracer_live_count / k_tracer_scan");
     return FS_OK;
 }
-int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, hipStream_t st)
+int tracer_compact(long n, float *const in[7], float *const out[7], const int *sums, long drop, bool removed_only, hipStream_t st)
 {
     TracerArrays a, b;
     for (int f = 0; f < 7; ++f) { a.a[f] = in[f]; b.a[f] = out[f]; }
-    hipLaunchKernelGGL(k_tracer_compact, dim3((unsigned)tracer_blocks(n)), dim3(256), 0, st, n, a, b, sums, drop);
+    hipLaunchKernelGGL(k_tracer_compact, dim3((unsigned)tracer_blocks(n)), dim3(256), 0, st, n, a, b, sums, drop, removed_only);
     FS_LAUNCH_CHECK("k_tracer_compact");
     return FS_OK;
 }
-int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, hipStream_t st)
+int tracer_spawn(long first, long j0, long count, float *const out[7], float x, float y, float radius, unsigned seed, int *perm, hipStream_t st)
 {
     if (count <= j0) return FS_OK;
     TracerArrays b;
     for (int f = 0; f < 7; ++f) b.a[f] = out[f];
-    hipLaunchKernelGGL(k_tracer_spawn, dim3((unsigned)((count - j0 + 255) / 256)), dim3(256), 0, st, first, j0, count, b, x, y, radius, seed);
+    hipLaunchKernelGGL(k_tracer_spawn, dim3((unsigned)((count - j0 + 255) / 256)), dim3(256), 0, st, first, j0, count, b, x, y, radius, seed, perm);
     FS_LAUNCH_CHECK("k_tracer_spawn");
     return FS_OK;
 }

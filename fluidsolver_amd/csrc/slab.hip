@@ -562,7 +562,8 @@ struct Planner {
             const fs_grid g = grid_of(c, 0);
             float *u = c->f[F_VEL].p(), *v = off(u, plane);
             const fs_particle_params pp = c->pparams;
-            const long n = c->n_particles;
+            // (slots rounded up to 16384, the empty ones hold life 0: a few tracers spawned do not change the node, context.hip)
+            const long n = std::min(c->max_particles, (c->n_particles + 16383L) & ~16383L);
             float *a0 = c->part[0], *a1 = c->part[1], *a2 = c->part[2], *a3 = c->part[3], *a4 = c->part[4],
                   *a5 = c->part[5], *a6 = c->part[6];
             compute("particles", g, 0, [=]() { return fs_k_particles_update(&g, u, v, &pp, n, a0, a1, a2, a3, a4, a5, a6, st); });

@@ -246,8 +246,8 @@ class ParticleSystem:
 
     def update(self, fluidSolver=None, windowSize=None):  # :242-304
         s = fluidSolver or self._solver
-        if not self.isEnabled or self.particleCount == 0:
-            return
+        if not self.isEnabled:   # (no tracers: the library returns at once; asking for the count here would make every frame wait
+            return               # for the compaction a spawn may have put off, see fs_particles_spawn)
         if windowSize is None:
             windowSize = (s.scaledWidth, s.scaledHeight)
         pp = self._pparams(windowSize)

@@ -378,14 +378,17 @@ int fs_particles_set_aos(fs_ctx *ctx, long n, const void *particles, size_t stri
 int fs_particles_get_aos(fs_ctx *ctx, long n, void *particles, size_t stride);
 int fs_default_particle_params(fs_particle_params *pp, float windowW, float windowH);
 int fs_particles_update(fs_ctx *ctx, const fs_particle_params *pp); /* Part:242-304 */
-long fs_particles_count(fs_ctx *ctx);
+long fs_particles_count(fs_ctx *ctx);   /* Part:229 particleCount; blocks when a spawn has put its compaction off (below) */
 /* ParticleSystem.addParticles(at:count:windowSize:), Part:186-231, on the device: `count` new tracers at (x, y) + U(-radius,
  * radius)^2 in window units (:202-205, spawnRadius :91), zero velocity (:208), life = alpha ~ U(0.3, 1) (:211, :221), mass ~
  * U(0.1, 1) (:212), age 0.  The reference's array is the live tracers in age order, appended to with removeFirst() at
  * maxParticles (:196-199): afterwards the context holds the last `max_particles` of (live tracers + new ones), in that order,
  * and no dead slots.  The reference draws from the system RNG; here tracer j of the call draws offset x, offset y, alpha, mass
  * from an xorshift32 stream seeded seed ^ (j + 1) * 0x9E3779B9, so a host that wants fresh tracers passes a fresh seed per
- * call.  Blocking, like fs_particles_set; single GPU. */
+ * call.  Single GPU.  While the new tracers fit behind the slots in use the call neither waits for the device nor touches
+ * the recorded frame graphs: the slots dead at that moment are only MARKED, and dropped by the next call that shows the
+ * arrays or their count to the host (fs_particles_get/_count/_set, fs_particle_lines*), which see exactly the state described
+ * above.  Once the slots run out the call compacts at once, which blocks (the live count comes back to the host). */
 int fs_particles_spawn(fs_ctx *ctx, float x, float y, long count, float radius, unsigned seed);
 /* (Re)allocate room for `capacity` tracers on this context; existing tracers are dropped.  On a slab this is
  * the only way to get tracer storage (capacity is per rank: leave headroom for tracers that migrate in). */

@@ -811,6 +811,52 @@ def test_spawn_on_device_matches_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_spawning_every_frame_keeps_the_frame_graphs(oracle):
+    # the interactive pattern of ContentView.swift:221-226: ten tracers per pointer event, every frame, tracer update inside the
+    # frame's graph.  No call looks at the tracers in between, so no spawn waits for the device and -- once recorded -- the
+    # graphs are replayed (no further instantiation); tracers die on the way (fast flow), and the final arrays, by slot,
+    # equal the oracle's spawn / update sequence
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    from oracle_binding import ParticleParams as OPP, VELOCITY, Params, full_grid
+    lib = L.load()
+    W, H, cap, params = 160, 120, 40000, (1.5e-4, 0.0, 0.5, 0.0, 0.002, 4)
+    s = FluidSolver(W, H, max_particles=cap)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    s.set_option(L.OPT_TRACER_SORT, 5)
+    ps = ParticleSystem(s)
+    ps.momentum = 0.9
+    ps.stepWithSolver((W, H))
+    o = oracle.solver(W, H)
+    p = Params(*params)
+    exp = [np.zeros(0, np.float32) for _ in range(7)]
+    st = (C.c_long * 3)()
+    try:
+        inst = []
+        for f in range(60):
+            pos, force, col = (30.0 + 2 * f, 60.0), (900.0, 300.0 - 10 * f), (10.0, 20.0, 30.0)
+            s.applyForce(pos, force, col)
+            o.add_force(pos, force, col, 5.0, p.deltaTime)
+            count = 2000 if f == 0 else 10          # (a first burst so that the arrays are large enough to be kept sorted)
+            L.check(lib.fs_particles_spawn(s.ctx, pos[0], pos[1], count, 15.0, 100 + f), s.ctx)
+            exp = oracle.particles_spawn(cap, exp, pos[0], pos[1], count, 15.0, 100 + f)
+            s.update()
+            o.update(p)
+            vel = o.field(VELOCITY)
+            oracle.particles_update(full_grid(W, H), vel[0], vel[1], OPP(0.9, 0.6, 3.0, 1, s.viscosity, W, H), exp)
+            L.check(lib.fs_graph_stats(s.ctx, st))
+            inst.append(st[2])
+        assert inst[-1] == inst[20], inst            # nothing instantiated over the last 40 frames
+        assert ps.particleCount == len(exp[0])
+        got = ps.get_arrays()
+        for name, a, b in zip("px py vx vy life mass age".split(), got, exp):
+            assert np.array_equal(a, b), name
+        assert (exp[4] == 0).any() and (exp[4] != 0).any() and len(exp[0]) < 2000 + 59 * 10   # tracers died and were dropped
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
 def test_config3_full_size_matches_oracle(oracle_omp):
     # BASELINE config 3 as bench.py runs it: 3072^2, N = 40, 1,048,576 tracers seeded as SURVEY 8(d) (xorshift32
     # 0x9E3779B9), the tracer update as the last node of the frame (FS_OPT_WITH_PARTICLES; frame 3 is a graph replay):
