@@ -349,7 +349,11 @@ def physical_roofline(ri, key, us_per_launch):
     if not e or not us_per_launch:
         return None
     t = us_per_launch * 1e-6
+    in_cache = key.endswith("_3072")
     return {"kernel": e["kernel"], "us_per_launch_live": us_per_launch, "us_per_launch_traced": e["traced_ns"] / 1e3,
+            "bytes_are": ("L2 <-> fabric bytes: at this size the loop's planes live in the 256 MB Infinity Cache, so hbm_frac here is a "
+                          "FABRIC fraction of the 8 TB/s figure, not DRAM traffic" if in_cache else
+                          "L2 <-> fabric bytes = DRAM bytes at this size (the planes are 1 GiB each)"),
             "hbm_bytes_per_launch_pmc": e["hbm_bytes"], "hbm_GBps": e["hbm_bytes"] / t / 1e9,
             "hbm_frac": e["hbm_bytes"] / t / (HBM_PEAK_GBS * 1e9),
             "valu_busy_frac": e["sq"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (256 * 4 * t * 2.4e9),
@@ -566,7 +570,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "effective_GBps": achieved, "traffic": None,
                 "note": "achieved/frac/effective_GBps = algorithmic bytes (12 B/cell/sweep x cells x sweeps per launch) / "
                         "HIP-event launch time: T sweeps share one pass over memory, so this is an effective figure "
-                        "and may exceed 1; hbm_frac = PMC bytes / launch time / 8 TB/s is the physical one"}
+                        "and may exceed 1; hbm_frac = PMC bytes / launch time / 8 TB/s is the physical one (at 3072^2 a fabric "
+                        "fraction: the planes sit in the Infinity Cache) and valu_issue.frac the share of the VALU pipes; the "
+                        "loop is bound by neither (DESIGN.md section 3)"}
         if ri is None:
             roof["traffic_withheld"] = why
         elif (W, H) == (3072, 3072):
