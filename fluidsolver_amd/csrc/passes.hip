@@ -388,13 +388,15 @@ struct __attribute__((packed, aligned(4))) TapPair {
 __device__ __forceinline__ TapPair ld_pair(const float *p) { return *reinterpret_cast<const TapPair *>(p); }
 
 template <int NP, bool FADE>
-__global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, const float *__restrict__ u,
+__global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, int hole_y, int hole_n, const float *__restrict__ u,
                                                 const float *__restrict__ v, const float *in,
                                                 float *__restrict__ out, size_t stride, float dt, int *err,
                                                 float fade_k)
 {
-    const Quad q = quad_of_thread(g, yb, ye);
+    // rows [yb, ye) less the hole_n rows from hole_y on: the two rims of a slab's split advection in one launch
+    Quad q = quad_of_thread(g, yb, ye - hole_n);
     if (!q.ok) return;
+    if (q.y >= hole_y) q.y += hole_n;
     const size_t o = row_off(g, q.y) + q.x;
     const float4 uu = ld4(u + o), vv = ld4(v + o);
     const float ux[4] = {uu.x, uu.y, uu.z, uu.w}, vy[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -1153,17 +1155,22 @@ int fs_k_renderSpeed(const fs_grid *g, const float *u, const float *v, float *ou
 }
 
 static int launch_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
-                         size_t plane_stride, float deltaTime, int *err_flag, bool fade, float fadeRate, void *stream)
+                         size_t plane_stride, float deltaTime, int *err_flag, bool fade, float fadeRate, void *stream,
+                         int hole_y = 0, int hole_n = 0)
 {
     CHECK_GRID(g);
     REQUIRE(u && v && in && out, "null pointer");
     REQUIRE(nplanes >= 1 && nplanes <= 3, "nplanes must be 1..3");
     REQUIRE(in != out, "advect cannot run in place");
     EMPTY_OK(g);
-    dim3 grid = quad_grid(g, 1);
+    REQUIRE(hole_n >= 0 && (hole_n == 0 || (hole_y >= g->yb && hole_y + hole_n <= g->ye)), "hole outside the rows of the launch");
+    fs_grid launched = *g;
+    launched.ye = g->ye - hole_n;
+    EMPTY_OK(&launched);
+    dim3 grid = quad_grid(&launched, 1);
     GK gk = make_gk(g);
     const float k = 1.0f - fadeRate;  // Shaders:331
-#define ADV(NP, FD) hipLaunchKernelGGL((k_advect<NP, FD>), grid, kBlock, 0, STREAM, gk, g->yb, g->ye, u, v, in, out, plane_stride, deltaTime, err_flag, k)
+#define ADV(NP, FD) hipLaunchKernelGGL((k_advect<NP, FD>), grid, kBlock, 0, STREAM, gk, g->yb, g->ye, hole_y, hole_n, u, v, in, out, plane_stride, deltaTime, err_flag, k)
     if (fade) {
         switch (nplanes) { case 1: ADV(1, true); break; case 2: ADV(2, true); break; default: ADV(3, true); break; }
     } else {
@@ -1238,6 +1245,17 @@ int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, f
 }
 
 }  // extern "C"
+
+// rows [g->yb, hole_y0) and [hole_y1, g->ye) in one launch (slab.hip: top and bottom rim of the split advection)
+namespace fs {
+int advect_around(const fs_grid *g, int hole_y0, int hole_y1, const float *u, const float *v, const float *in, float *out, int nplanes,
+                  size_t plane_stride, float deltaTime, int fade, float fadeRate, int *err_flag, void *stream)
+{
+    return launch_advect(g, u, v, in, out, nplanes, plane_stride, deltaTime, err_flag, fade != 0, fadeRate, stream, hole_y0,
+                         hole_y1 - hole_y0);
+}
+}  // namespace fs
+
 
 // The splat as a NODE of a frame's graph (context.hip): its argument block and launch geometry, set afresh before every
 // replay.  A splat that touches no cell keeps its node as one workgroup over an empty box.

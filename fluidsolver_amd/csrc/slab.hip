@@ -305,6 +305,34 @@ struct Planner {
         else
             compute("advect", g, np, [=]() { return fs_k_advect(&g, u, v, src, dst, np, plane, dt, err, st); });
     }
+    // the two rims [ya, yb) and [yc, yd) of a split advection.  Planned as two steps (the plan reads as it always did); when both
+    // have rows the first step launches them together (advect_around) and the second has nothing left to do: one launch
+    // and one dependency gap less per field for a slab with two neighbours
+    void advect_rims(int fi, bool fade, int ya, int yb, int yc, int yd)
+    {
+        const fs_grid ga = grid_rows(ya, yb), gb = grid_rows(yc, yd);
+        if (ga.ye <= ga.yb || gb.ye <= gb.yb || gb.yb < ga.ye) {
+            advect_rows(fi, fade, ya, yb);
+            advect_rows(fi, fade, yc, yd);
+            return;
+        }
+        Field &F = c->f[fi];
+        fs_grid g = ga;
+        g.ye = gb.ye;
+        const int h0 = ga.ye, h1 = gb.yb;
+        const bool vel_done = fi != F_VEL;
+        const float *u = vel_done ? c->f[F_VEL].p() : F.p(), *v = off(u, c->plane);
+        const float *src = F.p();
+        float *dst = F.t();
+        const int np = F.np;
+        const size_t plane = c->plane;
+        const float dt = c->params.deltaTime, fr = c->params.fadeSpeed;
+        int *err = c->err_flag;
+        hipStream_t st = c->stream;
+        const char *what = fade ? "advect_fade" : "advect";
+        compute(what, ga, np, [=]() { return advect_around(&g, h0, h1, u, v, src, dst, np, plane, dt, fade ? 1 : 0, fr, err, st); });
+        compute(what, gb, np, []() { return (int)FS_OK; });
+    }
     // both advections on rows [yb, ye) in one pass (FS_OPT_FUSE 1); no role swaps
     void advect_both_rows(int yb, int ye)
     {
@@ -498,13 +526,11 @@ struct Planner {
                 c->f[F_VEL].flip();
             }
             join(SLOT_VEL);
-            advect_rows(F_VEL, false, c->r0 - adv, i0);
-            advect_rows(F_VEL, false, i1, c->r1 + adv);
+            advect_rims(F_VEL, false, c->r0 - adv, i0, i1, c->r1 + adv);
             c->f[F_VEL].flip();                                                     // :558
             c->f[F_VEL].valid = adv;
             join(SLOT_DYE);
-            advect_rows(F_DYE, fade_fused, c->r0, i0);
-            advect_rows(F_DYE, fade_fused, i1, c->r1);
+            advect_rims(F_DYE, fade_fused, c->r0, i0, i1, c->r1);
             c->f[F_DYE].flip();                                                     // :584
         } else {
             if (multi) {
