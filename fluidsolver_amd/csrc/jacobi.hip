@@ -390,6 +390,10 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
         const int wup = wave > 0 ? wave - 1 : 0, wdn = wave < NW - 1 ? wave + 1 : NW - 1;
         xch[buf][wave][0][lane] = f4_of(p[0]);
         xch[buf][wave][1][lane] = f4_of(p[R - 1]);
+        // slabs: the workgroup's share of the CFL bound is gathered in LDS and leaves as ONE atomic (see below); every
+        // wave still here writes the same start values (wave 0 may have left already)
+        __shared__ unsigned wg_cfl[2];
+        if (A.cfl && lane == 0) { wg_cfl[0] = 0u; wg_cfl[1] = (unsigned)NW; }
         __syncthreads();
         Row prev = row_of(xch[buf][wup][1][lane]);
         const Row below = row_of(xch[buf][wdn][0][lane]);
@@ -427,9 +431,17 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
             }
             prev = c;
         }
-        if (A.cfl) {   // one atomicMax per wave (non-negative floats order like their bit patterns)
+        if (A.cfl) {
+            // non-negative floats order like their bit patterns.  Wave -> LDS -> one atomicMax per workgroup whose result
+            // nobody waits for: an atomic (or a look at the word first) per wave made every wave of the launch end on a round
+            // trip to one L2 channel, +17 us on the last launch of a 3072 x 1536 slab once the flow fills the grid
             for (int s = 32; s > 0; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s));
-            if (lane == 0 && vmax > 0.0f) atomic_max_if_larger(A.cfl, __float_as_uint(vmax));
+            if (lane == 0) {
+                atomicMax(&wg_cfl[0], __float_as_uint(vmax));
+                atomicMin(&wg_cfl[1], (unsigned)wave);
+            }
+            __syncthreads();
+            if (lane == 0 && (unsigned)wave == wg_cfl[1] && wg_cfl[0] != 0u) atomicMax(A.cfl, wg_cfl[0]);
         }
         FS_TL(3);
         return;
