@@ -23,5 +23,6 @@ te = time.perf_counter() - t0
 L.check(lib.fs_timer_end(s.ctx, C.byref(ms)), s.ctx)
 t = ms.value * 1e-3
 s.sync()
-print("single %dx%d: %.1f us/frame (host loop %.1f)" % (W, H, t / n * 1e6, te / n * 1e6), flush=True)
+tw = time.perf_counter() - t0
+print("single %dx%d: %.1f us/frame (host loop %.1f; wall to the end of a sync %.1f)" % (W, H, t / n * 1e6, te / n * 1e6, tw / n * 1e6), flush=True)
 s.close()
