@@ -1,4 +1,4 @@
-# kernel timelines of an inner slab (3072 x 1536 rows of 4) next to one context over the same rows
+# kernel timelines of an inner slab (3072 x [rows=1536] of [world=4]) next to one context over the same rows
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { # name, program args...
   name=$1; shift
@@ -10,6 +10,7 @@ run() { # name, program args...
   rm -rf gpurun_out/prof_$name
 }
 rm -f gpurun_out/r03_t_timelines.log
-export FS_H=1536
-run single1536 scripts/frames_only.py 60 && run inner scripts/frames_lone_slab.py 60 3072 1536 4 1
+export FS_H=${1:-1536}
+W=${2:-4}
+run single$FS_H scripts/frames_only.py 60 && run inner scripts/frames_lone_slab.py 60 3072 $FS_H $W 1
 cat gpurun_out/r03_t_timelines.log
