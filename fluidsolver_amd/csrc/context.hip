@@ -1086,12 +1086,39 @@ int fs_particles_get_aos(fs_ctx *c, long n, void *particles, size_t stride)
 int fs_particles_spawn(fs_ctx *c, float x, float y, long count, float radius, unsigned seed)
 {
     CTX(c);
-    SINGLE(c, "fs_particles_spawn");
     if (count < 0) { fs::set_error("negative spawn count"); return ctx_fail(c, FS_ERR_INVALID); }
     const long cap = c->max_particles;
     if (cap == 0) return FS_OK;   // (count == 0 still drops the dead slots: the reference's array never holds any)
     TRY(c, ensure_part_t(c));
     TRY(c, ensure_spawn_sums(c));
+    if (c->world > 1) {
+        // a slab: the same call on every rank, each appends ITS index block of the new tracers (tracer j's draws depend on
+        // (seed, j) alone), wherever they lie -- the next fs_step re-homes them like every other tracer.  A slab's arrays
+        // are in no order (the re-homing scatters), so there is no "oldest" to push out: dead slots are dropped when the
+        // room runs out, and a slab that is full of live tracers refuses.
+        TRY(c, fs::settle(c));
+        const long lo = (long)((__int128)count * c->rank / c->world), hi = (long)((__int128)count * (c->rank + 1) / c->world);
+        const long mine = hi - lo;
+        long n = c->n_particles;
+        if (n + mine > cap && n > 0) {
+            TRY(c, fs::tracer_count_live(n, c->part[4], c->spawn_sums, false, c->stream));
+            int live = 0;
+            TRYHIP(c, hipMemcpyAsync(&live, c->spawn_sums + fs::tracer_blocks(n), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            TRYHIP(c, hipStreamSynchronize(c->stream));
+            if ((long)live + mine <= cap) {
+                TRY(c, fs::tracer_compact(n, c->part, c->part_t, c->spawn_sums, 0, false, c->stream));
+                for (int i = 0; i < 7; ++i) std::swap(c->part[i], c->part_t[i]);
+                c->n_particles = n = live;
+            }
+        }
+        if (n + mine > cap) {
+            fs::set_error("rank %d would hold %ld tracers after the spawn, its capacity is %ld (fs_particles_reserve)", c->rank, n + mine, cap);
+            return ctx_fail(c, FS_ERR_NOMEM);
+        }
+        TRY(c, fs::tracer_spawn(n, lo, hi, c->part, x, y, radius, seed, nullptr, c->stream));
+        c->n_particles = n + mine;
+        return FS_OK;
+    }
     if (c->n_particles + count <= cap) {
         const long n = c->n_particles;
         TRY(c, fs::tracer_mark_removed(n, c->part[4], c->stream));

@@ -159,6 +159,12 @@ class _Slab:
         arrs = [np.ascontiguousarray(a, dtype=F) for a in (px, py, vx, vy, life, mass, age)]
         L.check(self.lib.fs_particles_set(self.ctx, len(arrs[0]), *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
 
+    def particles_spawn(self, at, count, radius=15.0, seed=0):
+        """ParticleSystem.addParticles on slabs (fs_particles_spawn): the same call on every rank; this rank appends its
+        index block of the new tracers, the next update() re-homes them."""
+        L.check(self.lib.fs_particles_spawn(self.ctx, float(at[0]), float(at[1]), int(count), float(radius), int(seed) & 0xFFFFFFFF),
+                self.ctx)
+
     def particles_get(self):
         """This rank's tracers, [7, n] (px, py, vx, vy, life, mass, age), in no particular order."""
         n = self.lib.fs_particles_count(self.ctx)

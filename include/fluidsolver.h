@@ -385,10 +385,14 @@ long fs_particles_count(fs_ctx *ctx);   /* Part:229 particleCount; blocks when a
  * maxParticles (:196-199): afterwards the context holds the last `max_particles` of (live tracers + new ones), in that order,
  * and no dead slots.  The reference draws from the system RNG; here tracer j of the call draws offset x, offset y, alpha, mass
  * from an xorshift32 stream seeded seed ^ (j + 1) * 0x9E3779B9, so a host that wants fresh tracers passes a fresh seed per
- * call.  Single GPU.  While the new tracers fit behind the slots in use the call neither waits for the device nor touches
+ * call.  While the new tracers fit behind the slots in use the call neither waits for the device nor touches
  * the recorded frame graphs: the slots dead at that moment are only MARKED, and dropped by the next call that shows the
  * arrays or their count to the host (fs_particles_get/_count/_set, fs_particle_lines*), which see exactly the state described
- * above.  Once the slots run out the call compacts at once, which blocks (the live count comes back to the host). */
+ * above.  Once the slots run out the call compacts at once, which blocks (the live count comes back to the host).
+ * On a slab the call is COLLECTIVE (same arguments on every rank): rank r appends tracers [count r / k, count (r+1) / k) of the
+ * call to its own arrays, wherever they lie, and the next fs_step re-homes them like every other tracer; the live tracers of
+ * all ranks together are the single-GPU result as a multiset.  A slab keeps no age order, so nothing is pushed out there: dead slots are
+ * dropped when room runs out, and FS_ERR_NOMEM says that the rank's capacity (fs_particles_reserve) is full of live tracers. */
 int fs_particles_spawn(fs_ctx *ctx, float x, float y, long count, float radius, unsigned seed);
 /* (Re)allocate room for `capacity` tracers on this context; existing tracers are dropped.  On a slab this is
  * the only way to get tracer storage (capacity is per rank: leave headroom for tracers that migrate in). */
@@ -425,9 +429,9 @@ int fs_set_particle_params(fs_ctx *ctx, const fs_particle_params *pp);
  * next fs_step deadlocks in a send/recv or computes on stale ghost rows:
  *     fs_step, fs_add_force (global coordinates), fs_set_params, fs_set_option, fs_reset, fs_write_field (it marks the
  *     ghost rows of that field stale on THIS rank; a neighbour that did not call it skips the refill), fs_particles_set,
- *     fs_set_particle_params, fs_comm_selftest, fs_destroy/fs_comm_destroy (order only).
+ *     fs_set_particle_params, fs_particles_spawn, fs_comm_selftest, fs_destroy/fs_comm_destroy (order only).
  * Rank-local (any rank, any time): fs_read_field, fs_field_device_ptr, fs_particles_get/_count, fs_particle_lines,
- * fs_slab_info/_stats/_waits, fs_sync, fs_last_error.  Single-GPU only: fs_stage, fs_particles_spawn.
+ * fs_slab_info/_stats/_waits, fs_sync, fs_last_error.  Single-GPU only: fs_stage.
  * RCCL is loaded at run time (FS_RCCL_LIBRARY if set, else a librccl already in the process, else the
  * default search path), so single-GPU hosts need none.
  * ---------------------------------------------------------------------- */

@@ -473,6 +473,84 @@ def test_tracer_capacity_is_checked():
         g.close()
 
 
+def _live(a):
+    a = np.asarray(a)
+    return _sorted_columns(a[:, a[4] != 0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spawning_on_slabs_equals_single_gpu(world):
+    """ParticleSystem.addParticles on slabs: fs_particles_spawn is collective, every rank appends its index block of the
+    new tracers and the next frame re-homes them.  With spawns between the frames the live tracers of all slabs together
+    must be the single-GPU live set, bit for bit."""
+    from fluidsolver_amd import FluidSolver, ParticleSystem
+    from fluidsolver_amd.native_slabs import LocalGroup
+    from fluidsolver_amd.script import splat
+    W, H, params, n, frames = 448, 420, (1.5e-4, 0.0, 0.5, 10.0, 0.002, 8), 6000, 7
+    arrs = _tracers(n, W, H)
+    arrs[4][::7] = 0.02                                  # some die on the way: the slabs keep their slots, one GPU drops them
+    g = LocalGroup(W, H, params, world, device=0, asynchronous=True)
+    s = FluidSolver(W, H, max_particles=4 * n)
+    (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = params
+    s.displayMode = None
+    ps = ParticleSystem(s)
+    ps.fluidForce, ps.linkToViscosity, ps.spawnRadius = 2.0, False, 40.0
+    ps.set_arrays(*arrs)
+    try:
+        for sl in g.slabs:
+            sl.particles_reserve(4 * n, fluidForce=2.0, linkToViscosity=False)
+            sl.particles_set(*arrs)
+        spawned = 0
+        for f in range(frames):
+            pos, force, col = splat(W, H, 9 * f + 1)
+            g.add_force(pos, force, col)
+            s.applyForce(pos, force, col)
+            at, count, seed = (pos[0], H * (0.1 + 0.13 * f)), 101 + 37 * f, 1000 + f   # near and across the slab borders
+            for sl in g.slabs:
+                sl.particles_spawn(at, count, radius=40.0, seed=seed)
+            ps.addParticles(at, count, seed=seed)
+            spawned += count
+            g.update()
+            s.update()
+            ps.update(s, (W, H))
+        g.sync()
+        s.sync()
+        parts = [sl.particles_get() for sl in g.slabs]
+        exp = _live(np.stack(ps.get_arrays()))
+        got = _live(np.concatenate(parts, axis=1))
+        assert exp.shape[1] > n - n // 7 and got.shape == exp.shape
+        assert np.array_equal(got, exp)
+        assert sum(sl.stats["tracers_received"] for sl in g.slabs) > 0
+    finally:
+        g.close()
+        s.close()
+
+
+def test_spawn_on_a_full_slab():
+    """A slab keeps no age order, so a spawn never pushes tracers out there: dead slots are dropped when room runs out, and a
+    rank full of live tracers refuses with FS_ERR_NOMEM."""
+    from fluidsolver_amd import lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup
+    W, H, params, n = 256, 240, (1.5e-4, 0.0, 0.5, 0.0, 0.002, 4), 4000
+    arrs = _tracers(n, W, H)
+    arrs[4][: n // 2] = 0.0                              # the first rank's index block is all dead slots
+    g = LocalGroup(W, H, params, 2, device=0)
+    try:
+        for sl in g.slabs:
+            sl.particles_reserve(n // 2 + 100)
+            sl.particles_set(*arrs)
+        for sl in g.slabs:                               # 100 each: fits behind the slots in use
+            sl.particles_spawn((100.0, 100.0), 200, seed=5)
+        assert [sl.lib.fs_particles_count(sl.ctx) for sl in g.slabs] == [n // 2 + 100, n // 2 + 100]
+        g.slabs[0].particles_spawn((100.0, 100.0), 600, seed=6)      # rank 0: room only once its dead slots are dropped
+        assert g.slabs[0].lib.fs_particles_count(g.slabs[0].ctx) == 100 + 300
+        with pytest.raises(L.FluidSolverError) as e:     # rank 1 is full of live tracers
+            g.slabs[1].particles_spawn((100.0, 100.0), 600, seed=6)
+        assert e.value.code == -3 and "capacity" in str(e.value)
+    finally:
+        g.close()
+
+
 def test_join_waits_are_measured():
     """FS_OPT_SLAB_PROFILE: every wait of a slab's kernels for halo rows is timed on the GPU (bench.py reports the
     sums at N > 1, so the next look at the links has data); results are unchanged by it."""
