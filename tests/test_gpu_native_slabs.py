@@ -551,6 +551,120 @@ def test_spawn_on_a_full_slab():
         g.close()
 
 
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("FS_FUZZ_SEEDS", "6"))))   # (more walks: FS_FUZZ_SEEDS=100)
+def test_random_walks_on_slabs_equal_single_gpu(seed):
+    """The slab frame is a state machine too (speculated halo depths checked one frame late, a third velocity buffer whose roles
+    rotate, replayed segments keyed by roles and row ranges, splats logged for a repair, ghost depths that survive or do not).
+    A random walk over what a host does -- splats of changing strength, frames, parameter and option changes on every rank,
+    reads in between, resets, spawns -- on 2-4 concurrent slabs against ONE context making the same moves: fields at random
+    checkpoints and at the end, and the live tracers as a multiset, bit for bit."""
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    from fluidsolver_amd.native_slabs import LocalGroup, make_params
+    rng = np.random.default_rng(7000 + seed)
+    world = int(rng.integers(2, 5))
+    W, H = (320, 96 * world + int(rng.integers(0, 7))) if seed % 2 else (448, 80 * world + 5)
+    par = [1.5e-4, 0.0, 0.2, 10.0, 0.002, 6]
+    tracers = seed % 3 == 0
+    cap = 20000
+    g = LocalGroup(W, H, tuple(par), world, device=0, asynchronous=bool(seed % 4), overlap=True)
+    s = FluidSolver(W, H, max_particles=cap if tracers else 0)
+    s.displayMode = None
+    ps = ParticleSystem(s) if tracers else None
+
+    def push():
+        (s.viscosity, s.diffusion, s.deltaTime, s.vorticityStrength, s.fadeSpeed, s.solverIterations) = par
+        p = make_params(tuple(par))
+        for sl in g.slabs:
+            L.check(sl.lib.fs_set_params(sl.ctx, C.byref(p)), sl.ctx)
+            sl.deltaTime, sl.viscosity = par[2], par[0]
+
+    def check(what):
+        g.sync()
+        s.sync()
+        assert np.array_equal(g.field("vel"), s.read_field(L.FIELD_VELOCITY)), (what, "velocity")
+        assert np.array_equal(g.field("dye"), s.read_field(L.FIELD_DENSITY)), (what, "dye")
+        if tracers:
+            got = _live(np.concatenate([sl.particles_get() for sl in g.slabs], axis=1))
+            exp = _live(np.stack(ps.get_arrays()))
+            assert got.shape == exp.shape and np.array_equal(got, exp), (what, "tracers")
+
+    log, flow_seen = [], False
+    try:
+        push()
+        if tracers:
+            ps.fluidForce, ps.linkToViscosity = 2.0, False
+            arrs = _tracers(6000, W, H, seed)
+            ps.set_arrays(*arrs)
+            for sl in g.slabs:
+                sl.particles_reserve(cap, fluidForce=2.0, linkToViscosity=False)
+                sl.particles_set(*arrs)
+        for it in range(50):
+            strength = float(rng.choice([10.0, 50.0, 150.0]))      # halo depths that jump: speculation misses
+            for _ in range(int(rng.integers(0, 3))):
+                pos = (float(rng.uniform(-5, W + 5)), float(rng.uniform(-5, H + 5)))
+                force = (float(rng.uniform(-strength, strength)), float(rng.uniform(-strength, strength)))
+                col = tuple(float(x) for x in rng.uniform(0, 40, 3))
+                g.add_force(pos, force, col)
+                s.applyForce(pos, force, col)
+            r = rng.random()
+            if tracers and r < 0.3:
+                at, count, sd = (float(rng.uniform(0, W)), float(rng.uniform(0, H))), int(rng.choice([1, 10, 300])), int(rng.integers(1, 2 ** 31))
+                for sl in g.slabs:
+                    sl.particles_spawn(at, count, radius=15.0, seed=sd)
+                ps.spawnRadius = 15.0
+                ps.addParticles(at, count, seed=sd)
+                log.append(("spawn", count))
+            r = rng.random()
+            if r < 0.08:
+                par[0] = float(rng.choice([1.5e-4, 3.0e-4, 0.0])); push(); log.append(("viscosity", par[0]))
+            elif r < 0.14:
+                par[3] = float(rng.choice([0.0, 10.0, 4.0])); push(); log.append(("vorticity", par[3]))
+            elif r < 0.18:
+                par[5] = int(rng.choice([6, 3, 8])); push(); log.append(("iterations", par[5]))
+            elif r < 0.22:
+                par[1] = float(rng.choice([0.0, 2.0e-4])); push(); log.append(("diffusion", par[1]))
+            elif r < 0.32:
+                opt, val = [(L.OPT_USE_GRAPH, int(rng.integers(0, 2))), (L.OPT_SLAB_DEFER, int(rng.integers(0, 2))),
+                            (L.OPT_SLAB_OVERLAP, int(rng.integers(0, 2))), (L.OPT_FUSE, int(rng.integers(0, 5))),
+                            (L.OPT_SPLIT_ROWS, int(rng.integers(0, 2))), (L.OPT_SEGMENT_GRAPH_AFTER, int(rng.integers(0, 4)))][int(rng.integers(0, 6))]
+                for sl in g.slabs:
+                    sl.set_option(opt, val)
+                log.append(("option", opt, val))
+            elif r < 0.35:
+                for sl in g.slabs:
+                    L.check(sl.lib.fs_reset(sl.ctx), sl.ctx)
+                s.reset(); log.append(("reset",))
+            elif r < 0.40:
+                k = int(rng.integers(0, world))
+                g.slabs[k].owned("dye"); log.append(("read", k))     # one rank looks at its rows: its owed halo check runs now
+            try:
+                g.update()
+            except L.FluidSolverError as e:
+                raise AssertionError((str(e), log[-15:], float(np.abs(s.read_field(L.FIELD_VELOCITY)[1]).max())))
+            s.update()
+            if tracers:
+                ps.update(s, (W, H))
+            log.append(("frame", it))
+            if rng.random() < 0.12:
+                check(log[-12:])
+            # (confinement without viscosity pumps the flow up; before the advection halo outgrows the ghost rows -- a
+            # legitimate FS_ERR_HALO -- start over.  Only the single context is looked at: the slabs are not made to wait)
+            vmax = float(np.abs(s.read_field(L.FIELD_VELOCITY)[1]).max())
+            flow_seen = flow_seen or vmax > 0
+            if vmax * par[2] > 0.3 * g.slabs[0].G:
+                for sl in g.slabs:
+                    L.check(sl.lib.fs_reset(sl.ctx), sl.ctx)
+                s.reset(); log.append(("reset (fast flow)",))
+        check(log[-12:])
+        assert flow_seen
+        if os.environ.get("FS_FUZZ_VERBOSE"):
+            print("seed", seed, "world", world, "redo", [sl.stats["redo"] for sl in g.slabs], g.slabs[0].graph_stats,
+                  "last halo", g.slabs[0].last_halo)
+    finally:
+        g.close()
+        s.close()
+
+
 def test_join_waits_are_measured():
     """FS_OPT_SLAB_PROFILE: every wait of a slab's kernels for halo rows is timed on the GPU (bench.py reports the
     sums at N > 1, so the next look at the links has data); results are unchanged by it."""

@@ -1031,3 +1031,97 @@ def test_jacobi_tuning_is_per_context():
         assert pa.value != pb.value        # odd number of launches: the sides alternate
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("FS_FUZZ_SEEDS", "6"))))   # (more walks: FS_FUZZ_SEEDS=100)
+def test_random_call_sequences_match_oracle(oracle, seed):
+    # The host side of a context is a state machine (graphs keyed by buffer roles / tracer bound / pending splats, parameter
+    # epochs, splats put off, tracers kept sorted, spawns that put their compaction off).  A random walk over the calls a host
+    # makes -- splats, spawns, frames, parameter and option changes, reads in between, resets -- against the oracle making the same
+    # moves: fields and all seven tracer arrays (by slot) at random checkpoints and at the end, bit for bit.
+    from fluidsolver_amd import FluidSolver, ParticleSystem, lib as L
+    from oracle_binding import DENSITY, PRESSURE, VELOCITY, ParticleParams as OPP, Params, full_grid
+    lib = L.load()
+    rng = np.random.default_rng(1000 + seed)
+    W, H, cap = (192, 160, 30000) if seed % 2 else (320, 96, 24000)
+    par = dict(viscosity=1.5e-4, diffusion=0.0, deltaTime=0.5, vorticityStrength=10.0, fadeSpeed=0.002, solverIterations=6)
+    s = FluidSolver(W, H, max_particles=cap)
+    s.displayMode = None
+    ps = ParticleSystem(s)
+    ps.momentum = 0.8
+    in_graph = bool(seed % 3)
+    o = oracle.solver(W, H)
+    exp = [np.zeros(0, F) for _ in range(7)]
+
+    def push():
+        for k, v in par.items():
+            setattr(s, k, v)
+        if in_graph:
+            ps.stepWithSolver((W, H))
+
+    def check(what):
+        s.sync()
+        assert np.array_equal(s.read_field(L.FIELD_VELOCITY), o.field(VELOCITY)), (what, "velocity")
+        assert np.array_equal(s.read_field(L.FIELD_DENSITY), o.field(DENSITY)), (what, "dye")
+        assert np.array_equal(s.read_field(L.FIELD_PRESSURE), o.field(PRESSURE)), (what, "pressure")
+        assert ps.particleCount == len(exp[0]), what
+        for name, a, b in zip("px py vx vy life mass age".split(), ps.get_arrays(), exp):
+            assert np.array_equal(a, b), (what, name)
+
+    push()
+    s.set_option(L.OPT_TRACER_SORT, int(rng.integers(2, 6)))
+    log = []
+    try:
+        for it in range(70):
+            for _ in range(int(rng.integers(0, 3))):
+                pos = (float(rng.uniform(-5, W + 5)), float(rng.uniform(-5, H + 5)))
+                force = (float(rng.uniform(-900, 900)), float(rng.uniform(-900, 900)))
+                col = tuple(float(x) for x in rng.uniform(0, 40, 3))
+                s.applyForce(pos, force, col)
+                o.add_force(pos, force, col, s.forceRadius, par["deltaTime"])
+            r = rng.random()
+            if it == 0 or r < 0.45:
+                count = 18000 if it == 0 else int(rng.choice([0, 1, 10, 10, 300, 9000]))
+                x, y, sd = float(rng.uniform(0, W)), float(rng.uniform(0, H)), int(rng.integers(1, 2 ** 31))
+                L.check(lib.fs_particles_spawn(s.ctx, x, y, count, 15.0, sd), s.ctx)
+                exp = oracle.particles_spawn(cap, exp, x, y, count, 15.0, sd)
+                log.append(("spawn", count))
+            r = rng.random()
+            if r < 0.08:
+                par["viscosity"] = float(rng.choice([1.5e-4, 3.0e-4, 0.0]))
+                push(); log.append(("viscosity", par["viscosity"]))
+            elif r < 0.14:
+                par["vorticityStrength"] = float(rng.choice([0.0, 10.0, 4.0]))
+                push(); log.append(("vorticity", par["vorticityStrength"]))
+            elif r < 0.18:
+                par["solverIterations"] = int(rng.choice([6, 3, 9]))
+                push(); log.append(("iterations", par["solverIterations"]))
+            elif r < 0.22:
+                par["diffusion"] = float(rng.choice([0.0, 2.0e-4]))
+                push(); log.append(("diffusion", par["diffusion"]))
+            elif r < 0.27:
+                opt, val = [(L.OPT_USE_GRAPH, int(rng.integers(0, 2))), (L.OPT_SPLAT_IN_GRAPH, int(rng.integers(0, 2))),
+                            (L.OPT_FUSE, int(rng.integers(0, 5))), (L.OPT_SPLIT_ROWS, int(rng.integers(0, 2))),
+                            (L.OPT_SPLIT_PLANES, int(rng.integers(0, 2))), (L.OPT_TRACER_SORT, int(rng.integers(0, 6)))][int(rng.integers(0, 6))]
+                s.set_option(opt, val); log.append(("option", opt, val))
+            elif r < 0.30:
+                s.reset(); o.reset(); log.append(("reset",))
+            elif r < 0.34:
+                list(ps.lineVertices((W, H), 1.5)); log.append(("lines",))
+            elif r < 0.38:
+                assert ps.particleCount == len(exp[0]), log
+            s.update()
+            if not in_graph:
+                ps.update(s, (W, H))
+            o.update(Params(*[par[k] for k in ("viscosity", "diffusion", "deltaTime", "vorticityStrength", "fadeSpeed", "solverIterations")]))
+            if len(exp[0]):
+                vel = o.field(VELOCITY)
+                oracle.particles_update(full_grid(W, H), vel[0], vel[1], OPP(0.8, 0.6, 3.0, 1, par["viscosity"], W, H), exp)
+            log.append(("frame", it))
+            if rng.random() < 0.12:
+                check(log[-12:])
+        check(log[-12:])
+        assert (exp[4] != 0).any()
+    finally:
+        s.close()
