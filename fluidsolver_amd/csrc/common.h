@@ -11,9 +11,11 @@ struct GK {
     int W, H;      // global domain
     int pitch;     // floats per row (multiple of 64)
     int y0, rows;  // buffer holds global rows [y0, y0+rows)
+    int nt;        // planes too big to be found in a cache again: results leave through streaming stores (st4s); bit 0 passes, bit 1 Jacobi
 };
 
-inline GK make_gk(const fs_grid *g) { return GK{g->width, g->height, g->pitch, g->y0, g->rows}; }
+int stream_stores(const fs_grid *g);   // context.hip: the size rule
+inline GK make_gk(const fs_grid *g) { return GK{g->width, g->height, g->pitch, g->y0, g->rows, stream_stores(g)}; }
 
 // Tuning of the two Jacobi loops.  One process-wide default (fs_config_set: what the per-kernel entry points fs_k_*_n use and
 // what a new context starts from) and one copy per context (fs_set_option), so two contexts never change each other's.
@@ -122,6 +124,18 @@ inline unsigned xcd_pad_rows(unsigned tile_rows, unsigned m) { return (tile_rows
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// a result plane's store: nontemporal when the plane is too big to be read back from a cache (GK::nt; BIT: which class of kernel asks)
+template <int BIT = 1>
+__device__ __forceinline__ void st4s(float *p, float4 v, const GK &g)
+{
+    if (g.nt & BIT) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v x = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p));
+    } else {
+        st4(p, v);
+    }
+}
 
 // max into a device word that thousands of waves share (the CFL bound of a slab): the value only grows, so a wave that
 // reads it first -- straight from L2; a stale, smaller reading merely costs the atomic it would have saved -- and finds

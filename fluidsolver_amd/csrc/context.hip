@@ -59,6 +59,19 @@ int ctx_fail(fs_ctx *c, int rc)
 
 }  // namespace fs
 
+namespace fs {
+// GK::nt, the size rule of the streaming stores (common.h st4s): bit 0 = the single passes, bit 1 = the Jacobi launches.  A plane
+// that is far from fitting the 256 MB Infinity Cache beside the other planes of its pass is gone from every cache before anything
+// reads it back, and a store that says so leaves the lines that ARE about to be re-read (stencil neighbours, gather taps) alone.
+// Frames, streaming stores off / passes / Jacobi / both (profiles/r03_z_streaming_stores.log): 16384^2 (1 GB planes) 11832 /
+// 11684 / 11672 / 11559 us; 16384 x 2048 (128 MB) 1585 / 1575 / 1545 / 1546; 6144^2 (151 MB) 1788 / 1791 / 1749 / 1752; 4096^2
+// (67 MB) 826 / 817 / 826 / 825; 3072^2 (37 MB) 464 / -- / -- / 478.  So: both from 96 MB per plane on, none below.
+int stream_stores(const fs_grid *g)
+{
+    return (double)g->pitch * (double)g->rows * sizeof(float) >= 96.0 * 1024 * 1024 ? 3 : 0;
+}
+}  // namespace fs
+
 using namespace fs;
 
 static void drop_graphs(fs_ctx *c)

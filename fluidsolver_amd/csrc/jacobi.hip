@@ -363,7 +363,7 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
             dv.z = (rf || fx2) ? 0.0f : -0.5f * ((uc.w - uc.y) + (vb.z - vt.z));
             dv.w = (rf || fx3) ? 0.0f : -0.5f * ((ur - uc.z) + (vb.w - vt.w));
             d[i] = row_of(dv);
-            if (col_st && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) st4(A.div_out + row_off(g, y) + gx, dv);
+            if (col_st && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) st4s<2>(A.div_out + row_off(g, y) + gx, dv, g);
             vt = vr[i];
         }
     }
@@ -408,7 +408,7 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
             const int y = wy0 + i;
             if (col_out && ty >= A.TE && ty < TH - A.TE && y >= A.yb && y < A.ye) {
                 const size_t o = row_off(g, y) + gx;
-                st4(out + o, f4_of(c));
+                st4s<2>(out + o, f4_of(c), g);
                 const bool rf = (rowfixed >> i) & 1u;      // boundary rows keep their velocity (Shaders:230-233)
                 if (!rf || A.cfl) {
                     float4 uu = ld4(A.gu + o), vv = ld4(A.gv + o);
@@ -418,8 +418,8 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
                         if (!fx1) { uu.y = uu.y - 0.5f * (c.b.x - c.a.x); vv.y = vv.y - 0.5f * (nx.a.y - prev.a.y); }
                         if (!fx2) { uu.z = uu.z - 0.5f * (c.b.y - c.a.y); vv.z = vv.z - 0.5f * (nx.b.x - prev.b.x); }
                         if (!fx3) { uu.w = uu.w - 0.5f * (rw - c.b.x);    vv.w = vv.w - 0.5f * (nx.b.y - prev.b.y); }
-                        st4(A.gu + o, uu);
-                        st4(A.gv + o, vv);
+                        st4s<2>(A.gu + o, uu, g);
+                        st4s<2>(A.gv + o, vv, g);
                     }
                     if (A.cfl) {   // padding columns are don't-care
                         if (gx + 0 < g.W) vmax = fmaxf(vmax, fabsf(vv.x));
@@ -451,7 +451,7 @@ __device__ __forceinline__ void tile_body(const JacobiArgs &A, const GK &g, floa
         for (int i = 0; i < R; ++i) {
             const int ty = wave * R + i;
             const int y = wy0 + i;
-            if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4(out + row_off(g, y) + gx, f4_of(p[i]));
+            if (ty >= A.T && ty < TH - A.T && y >= A.yb && y < A.ye) st4s<2>(out + row_off(g, y) + gx, f4_of(p[i]), g);
         }
     }
     FS_TL(3);

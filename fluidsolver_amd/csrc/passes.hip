@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_divergence(GK g, int yb, int ye, const 
     o.y = is_boundary(g, q.x + 1, q.y) ? 0.0f : -0.5f * ((ur.y - ul.y) + (vb.y - vt.y));
     o.z = is_boundary(g, q.x + 2, q.y) ? 0.0f : -0.5f * ((ur.z - ul.z) + (vb.z - vt.z));
     o.w = is_boundary(g, q.x + 3, q.y) ? 0.0f : -0.5f * ((ur.w - ul.w) + (vb.w - vt.w));
-    st4(div + row_off(g, q.y) + q.x, o);
+    st4s(div + row_off(g, q.y) + q.x, o, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_vorticity(GK g, int yb, int ye, const f
     o.y = is_boundary(g, q.x + 1, q.y) ? 0.0f : (ub.y - ut.y) - (vr.y - vl.y);
     o.z = is_boundary(g, q.x + 2, q.y) ? 0.0f : (ub.z - ut.z) - (vr.z - vl.z);
     o.w = is_boundary(g, q.x + 3, q.y) ? 0.0f : (ub.w - ut.w) - (vr.w - vl.w);
-    st4(w + row_off(g, q.y) + q.x, o);
+    st4s(w + row_off(g, q.y) + q.x, o, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -116,8 +116,8 @@ __device__ __forceinline__ float subtract_gradient_quad(const GK &g, const Quad 
     if (!is_boundary(g, q.x + 1, q.y)) { uu.y = uu.y - 0.5f * (pr.y - pl.y); vv.y = vv.y - 0.5f * (pb.y - pt.y); }
     if (!is_boundary(g, q.x + 2, q.y)) { uu.z = uu.z - 0.5f * (pr.z - pl.z); vv.z = vv.z - 0.5f * (pb.z - pt.z); }
     if (!is_boundary(g, q.x + 3, q.y)) { uu.w = uu.w - 0.5f * (pr.w - pl.w); vv.w = vv.w - 0.5f * (pb.w - pt.w); }
-    st4(u + o, uu);
-    st4(v + o, vv);
+    st4s(u + o, uu, g);
+    st4s(v + o, vv, g);
     // |v| of the cells inside the domain (padding columns are don't-care)
     float m = fabsf(vv.x);
     if (q.x + 1 < g.W) m = fmaxf(m, fabsf(vv.y));
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void k_vorticity_apply(GK g, int yb, int ye, c
     if (!is_boundary(g, x + 2, y)) vort_force(w1, w3, t2, b2, w2, strength, dt, uu.z, vv.z);
     if (!is_boundary(g, x + 3, y)) vort_force(w2, wr, t3, b3, w3, strength, dt, uu.w, vv.w);
     const size_t o = row_off(g, y) + x;
-    st4(uo + o, uu);
-    st4(vo + o, vv);
+    st4s(uo + o, uu, g);
+    st4s(vo + o, vv, g);
 }
 
 // The same fusion for planes that FIT the cache, where re-reading rows buys nothing and the two streaming kernels used to
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void k_vorticity_apply_march(GK g, int yb, int
         if (!is_boundary(g, x + 3, y)) vort_force(wc.z, wr, wt.w, wb.w, wc.w, strength, dt, uu.w, vv.w);
         if (stores) {
             const size_t o = row_off(g, y) + x;
-            st4(uo + o, uu);
-            st4(vo + o, vv);
+            st4s(uo + o, uu, g);
+            st4s(vo + o, vv, g);
         }
         wt = wc; wc = wb;
         u_c = u_p1; u_p1 = u_p2;
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(256) void k_apply_vorticity(GK g, int yb, int ye, c
     if (!is_boundary(g, q.x + 1, q.y)) vort_force(wl.y, wr.y, wt.y, wb.y, wn.c.y, strength, dt, uu.y, vv.y);
     if (!is_boundary(g, q.x + 2, q.y)) vort_force(wl.z, wr.z, wt.z, wb.z, wn.c.z, strength, dt, uu.z, vv.z);
     if (!is_boundary(g, q.x + 3, q.y)) vort_force(wl.w, wr.w, wt.w, wb.w, wn.c.w, strength, dt, uu.w, vv.w);
-    st4(u + o, uu);
-    st4(v + o, vv);
+    st4s(u + o, uu, g);
+    st4s(v + o, vv, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_advect(GK g, int yb, int ye, int hole_y
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j] * fade_k, 0.0f);
         }
-        st4(out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]));
+        st4s(out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]), g);
     }
 }
 
@@ -531,8 +531,8 @@ __global__ __launch_bounds__(256, 8) void k_advect_both(GK g, int yb, int ye, co
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (bnd[j]) { nu[j] = ux[j]; nv[j] = vy[j]; }             // boundary cells copy the input, :127-130
-    st4(uo + o, make_float4(nu[0], nu[1], nu[2], nu[3]));
-    st4(vo + o, make_float4(nv[0], nv[1], nv[2], nv[3]));
+    st4s(uo + o, make_float4(nu[0], nu[1], nu[2], nu[3]), g);
+    st4s(vo + o, make_float4(nv[0], nv[1], nv[2], nv[3]), g);
     // the dye, through the velocity just computed (Solver:577-582 binds the swapped velocity texture)
     short_halo |= backtrace4(g, q, nu, nv, dt, bnd, t);
     if (short_halo && err) atomicOr(err, 1);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 8) void k_advect_both(GK g, int yb, int ye, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j] * fade_k, 0.0f);
         }
-        st4(dye_out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]));
+        st4s(dye_out + c * stride + o, make_float4(r[0], r[1], r[2], r[3]), g);
     }
 }
 
