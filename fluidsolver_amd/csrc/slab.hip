@@ -74,8 +74,10 @@ bool bands_wanted(const fs_ctx *c, int N)
     // a slab: its own rows (the nominal height, so that every rank decides alike) plus the ghost rows the loop reads
     const int rows = c->world > 1 ? c->H / c->world : c->H;
     const double loop_rows = c->world > 1 ? (double)(rows + 2 * (N + 1)) : (double)rows;
-    const bool cache_resident = 3.0 * (double)c->pitch * loop_rows * sizeof(float) < 192.0 * 1024 * 1024;
-    if (!(c->fuse >= 3 || (c->fuse == 1 && cache_resident))) return false;
+    if (!(c->fuse >= 3 || c->fuse == 1)) return false;
+    // (planes of half a GB and more: one chain, the bands cost 0.5 % at 16384^2; below, -1.5 % at 8192^2 .. -4.5 % at 6144^2,
+    // profiles/r03_z_projection_beyond_cache.log)
+    if ((double)c->pitch * loop_rows * sizeof(float) >= 512.0 * 1024 * 1024) return false;
     if (c->world > 1 && c->G < N + 1) return false;   // the fused projection needs N + 1 ghost rows of velocity
     const int T = std::min(c->tuning.depth[0], N), oh = std::max(8, 64 - 2 * T);   // (the default 256 x 64 tile)
     const long tiles = (long)((c->W + 231) / 232) * (long)((rows + oh - 1) / oh);
@@ -415,11 +417,11 @@ struct Planner {
             sweeps(false, F_VEL, N, need_v2);
         }
         need(F_VEL, need_v2);
-        // The projection in one loop (fs_k_project_n): while the loop's planes sit in the Infinity Cache.  A slab needs
-        // N + 1 ghost rows of velocity for it (it has them whenever the capacity allows: need_v2 = N + 1).
-        const double loop_rows = multi ? (double)(c->H / c->world + 2 * (N + 1)) : (double)c->H;   // the same on every rank
-        const bool cache_resident = 3.0 * (double)c->pitch * loop_rows * sizeof(float) < 192.0 * 1024 * 1024;
-        const bool project_fused = (c->fuse >= 3 || (c->fuse == 1 && cache_resident)) && N > 0 && (!multi || G >= N + 1);
+        // The projection in one loop (fs_k_project_n).  A slab needs N + 1 ghost rows of velocity for it (it has them whenever
+        // the capacity allows: need_v2 = N + 1).  Rounds 1 and 2 kept the separate divergence and gradient passes beyond the
+        // Infinity Cache (+0.3 % for the loop there); with the streaming stores of round 3 the loop wins at every size
+        // (-2.9 % per frame at 16384^2, profiles/r03_z_projection_beyond_cache.log)
+        const bool project_fused = (c->fuse >= 3 || c->fuse == 1) && N > 0 && (!multi || G >= N + 1);
         const int dd = multi ? std::min(need_div, eff(F_VEL) - 1) : 0;
         if (!project_fused) {
             const fs_grid g = grid_of(c, dd);
@@ -429,10 +431,9 @@ struct Planner {
         if (multi) c->f[F_DIV].valid = dd;
         c->p_zero = true;                                                             // clear folded in, :528-530
         c->f[F_P].valid = kInf;
-        // one GPU: the divergence is computed by the first pressure launch and the gradient is subtracted by the last pressure launch, from registers (FS_OPT_FUSE).  Pays while
-        // the loop is VALU-bound, i.e. while its planes sit in the Infinity Cache (-10 us of 597 at 3072^2); at
-        // 16384^2 the loop streams from HBM, the extra 16 B/cell no longer ride for free and it costs 0.3 %
-        // (profiles/r01_h_ab_fuse*.log), so the separate pass is kept there.
+        // the divergence is computed by the first pressure launch and the gradient is subtracted by the last pressure launch,
+        // from registers (FS_OPT_FUSE): -10 us of 597 at 3072^2 (profiles/r01_h_ab_fuse*.log), -2.9 % at 16384^2 once the result
+        // planes leave through streaming stores (see project_fused above)
         const bool grad_fused = project_fused;
         if (project_fused && multi) {
             const fs_grid g = grid_of(c, 0);

@@ -391,11 +391,9 @@ class SlabSolver:
             self._sweeps("diffuse", "vel", N, need_v2)
         self._need("vel", need_v2)
         # The projection in one loop (fs_k_project_n): the divergence is computed by the first pressure launch and the
-        # gradient subtracted by the last, from registers -- while the loop's planes sit in the Infinity Cache (beyond
-        # that separate passes are faster).  A slab needs N + 1 ghost rows of velocity for it.
-        loop_rows = (self.H // self.world + 2 * (N + 1)) if multi else self.H      # the same on every rank
-        cache_resident = 3.0 * self.pitch * loop_rows * 4 < 192.0 * 1024 * 1024
-        grad_fused = (N > 0 and cache_resident and hasattr(self.be, "project_n")
+        # gradient subtracted by the last, from registers -- at every size since round 3 (slab.hip plan_a).  A slab needs
+        # N + 1 ghost rows of velocity for it.
+        grad_fused = (N > 0 and hasattr(self.be, "project_n")
                       and (not multi or (self.G >= N + 1 and hasattr(self.be, "project_n_cfl"))))
         dd = min(need_div, eff("vel") - 1) if multi else 0
         if not grad_fused:
