@@ -279,8 +279,8 @@ enum { FS_OPT_USE_GRAPH = 0,      /* 1 (default): replay update() as a hipGraph 
                                      Jacobi workgroup, so one workgroup of a CU loads while the other sweeps */
        FS_OPT_STAGGER_MODE = 8,   /* which workgroups are held back, 0..3 (tuning) */
        FS_OPT_BAND_DELAY = 14,    /* two-band projection: head start of the upper band, in 10 ns ticks (default 100; tuning) */
-       FS_OPT_SPLIT_ROWS = 13,    /* 1 (default): on one GPU, when the projection runs as one fused loop of at least two launches on a
-                                     grid of >= 768 tiles, the loop runs as two row bands on two streams, each computing the
+       FS_OPT_SPLIT_ROWS = 13,    /* 1 (default): when the projection runs as one fused loop of at least two launches on a grid (or
+                                     slab) of >= 768 tiles whose planes are below 512 MB, the loop runs as two row bands on two streams, each computing the
                                      rows beside the split redundantly (no exchange); the holes one chain of launches leaves
                                      (partly filled last round, workgroups loading) are filled by the other; same bits;
                                      0 = one chain */
