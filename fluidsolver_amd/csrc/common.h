@@ -52,9 +52,9 @@ struct SplatNode {
 };
 void splat_node_params(SplatNode &sn, const fs_grid *g, float *u, float *v, float *r, float *gch, float *b, const float s[9]);
 
-// k_advect on rows [g->yb, hole_y0) and [hole_y1, g->ye) in one launch (passes.hip)
+// k_advect on rows [g->yb, hole_y0) and [hole_y1, g->ye) in one launch (passes.hip); stream_result: streaming stores regardless of size
 int advect_around(const fs_grid *g, int hole_y0, int hole_y1, const float *u, const float *v, const float *in, float *out, int nplanes,
-                  size_t plane_stride, float deltaTime, int fade, float fadeRate, int *err_flag, void *stream);
+                  size_t plane_stride, float deltaTime, int fade, float fadeRate, int *err_flag, void *stream, int stream_result);
 
 void set_error(const char *fmt, ...);
 const char *get_error();

@@ -1156,7 +1156,7 @@ int fs_k_renderSpeed(const fs_grid *g, const float *u, const float *v, float *ou
 
 static int launch_advect(const fs_grid *g, const float *u, const float *v, const float *in, float *out, int nplanes,
                          size_t plane_stride, float deltaTime, int *err_flag, bool fade, float fadeRate, void *stream,
-                         int hole_y = 0, int hole_n = 0)
+                         int hole_y = 0, int hole_n = 0, int stream_result = 0)
 {
     CHECK_GRID(g);
     REQUIRE(u && v && in && out, "null pointer");
@@ -1169,6 +1169,7 @@ static int launch_advect(const fs_grid *g, const float *u, const float *v, const
     EMPTY_OK(&launched);
     dim3 grid = quad_grid(&launched, 1);
     GK gk = make_gk(g);
+    if (stream_result) gk.nt |= 1;   // (the caller knows that nothing reads the result soon: slab.hip dye_result_streams)
     const float k = 1.0f - fadeRate;  // Shaders:331
 #define ADV(NP, FD) hipLaunchKernelGGL((k_advect<NP, FD>), grid, kBlock, 0, STREAM, gk, g->yb, g->ye, hole_y, hole_n, u, v, in, out, plane_stride, deltaTime, err_flag, k)
     if (fade) {
@@ -1246,13 +1247,14 @@ int fs_k_addForces(const fs_grid *g, float *u, float *v, float *r, float *gch, f
 
 }  // extern "C"
 
-// rows [g->yb, hole_y0) and [hole_y1, g->ye) in one launch (slab.hip: top and bottom rim of the split advection)
+// rows [g->yb, hole_y0) and [hole_y1, g->ye) in one launch (slab.hip: top and bottom rim of the split advection; hole_y0 ==
+// hole_y1: all rows); stream_result: the result leaves through streaming stores whatever the size rule says
 namespace fs {
 int advect_around(const fs_grid *g, int hole_y0, int hole_y1, const float *u, const float *v, const float *in, float *out, int nplanes,
-                  size_t plane_stride, float deltaTime, int fade, float fadeRate, int *err_flag, void *stream)
+                  size_t plane_stride, float deltaTime, int fade, float fadeRate, int *err_flag, void *stream, int stream_result)
 {
     return launch_advect(g, u, v, in, out, nplanes, plane_stride, deltaTime, err_flag, fade != 0, fadeRate, stream, hole_y0,
-                         hole_y1 - hole_y0);
+                         hole_y1 - hole_y0, stream_result);
 }
 }  // namespace fs
 

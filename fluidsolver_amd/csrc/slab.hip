@@ -288,6 +288,19 @@ struct Planner {
         }
     }
 
+    // The advected dye is read next by the NEXT frame's dye advection, a frame of other traffic away.  When the planes are of
+    // the size at which the just-advected velocity and the dye read here still fit the 256 MB Infinity Cache together
+    // (2 + 3 planes) but not with the dye written as well (+ 3), the result leaves through streaming stores and the velocity
+    // is still there for the next frame's curl and diffuse launches: 463.5 -> 457.2 us per frame at 3072^2 (37.7 MB planes);
+    // at 4096^2 (67 MB) nothing of that fits either way and the hint costs 0.6 % (profiles/r03_z_streaming_stores.log).  Not
+    // when the display pass reads the dye right behind.  (From 96 MB on every result streams, common.h st4s.)
+    bool dye_result_streams(int fi) const
+    {
+        if (fi != F_DYE || c->fuse != 1 || c->dry) return false;
+        if (c->params.displayMode == FS_DISPLAY_DENSITY) return false;
+        const double P = (double)c->pitch * (double)(c->b1 - c->b0) * sizeof(float);
+        return 8.0 * P > 256.0 * 1024 * 1024 && 5.0 * P <= 256.0 * 1024 * 1024;
+    }
     // advect field fi on rows [yb, ye) (no role swap: the caller swaps once all parts are planned)
     void advect_rows(int fi, bool fade, int yb, int ye)
     {
@@ -302,7 +315,10 @@ struct Planner {
         const float dt = c->params.deltaTime, fr = c->params.fadeSpeed;
         int *err = c->err_flag;
         hipStream_t st = c->stream;
-        if (fade)
+        if (dye_result_streams(fi))
+            compute(fade ? "advect_fade" : "advect", g, np,
+                    [=]() { return advect_around(&g, g.yb, g.yb, u, v, src, dst, np, plane, dt, fade ? 1 : 0, fr, err, st, 1); });
+        else if (fade)
             compute("advect_fade", g, np, [=]() { return fs_k_advect_fade(&g, u, v, src, dst, np, plane, dt, fr, err, st); });
         else
             compute("advect", g, np, [=]() { return fs_k_advect(&g, u, v, src, dst, np, plane, dt, err, st); });
@@ -332,7 +348,8 @@ struct Planner {
         int *err = c->err_flag;
         hipStream_t st = c->stream;
         const char *what = fade ? "advect_fade" : "advect";
-        compute(what, ga, np, [=]() { return advect_around(&g, h0, h1, u, v, src, dst, np, plane, dt, fade ? 1 : 0, fr, err, st); });
+        const int streams = dye_result_streams(fi) ? 1 : 0;
+        compute(what, ga, np, [=]() { return advect_around(&g, h0, h1, u, v, src, dst, np, plane, dt, fade ? 1 : 0, fr, err, st, streams); });
         compute(what, gb, np, []() { return (int)FS_OK; });
     }
     // both advections on rows [yb, ye) in one pass (FS_OPT_FUSE 1); no role swaps
