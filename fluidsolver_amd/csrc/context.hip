@@ -78,7 +78,7 @@ static void drop_graphs(fs_ctx *c)
 {
     c->stable_frames = 0;
     fs::drop_segment_graphs(c);
-    // (a replay may still be running: this runtime does not put the destruction of an executing graph off)
+    // (a replay may still be running, and not every runtime puts the destruction of an executing graph off; drops are rare)
     if (!c->graphs.empty() && c->stream && !c->dry) (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto &kv : c->graphs_src) (void)hipGraphDestroy(kv.second);

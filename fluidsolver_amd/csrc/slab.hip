@@ -1298,7 +1298,7 @@ int settle(fs_ctx *c)
 void drop_segment_graphs(fs_ctx *c)
 {
     if (c->seg_graphs.empty()) return;
-    // (a replay may still be running: this runtime does not put the destruction of an executing graph off)
+    // (a replay may still be running, and not every runtime puts the destruction of an executing graph off; drops are rare)
     if (c->stream && !c->dry) (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->seg_graphs) (void)hipGraphExecDestroy(kv.second);
     c->seg_graphs.clear();
